@@ -1,0 +1,133 @@
+/*
+ * rbvfit_amd.h -- C ABI of the MI355X-native Voigt forward-model + log-likelihood engine.
+ *
+ * This is the drop-in boundary for ONE path of rongmon/rbvfit: the per-walker evaluation
+ *     CompiledVoigtModel.model_flux(theta, wave)      src/rbvfit/core/voigt_model.py:295-311
+ *       -> _evaluate_compiled_model                   src/rbvfit/core/voigt_model.py:162-261
+ *       -> _vectorized_voigt_tau                      src/rbvfit/core/voigt_model.py:100-159
+ *     vfit.lnprior / lnlike / lnprob                  src/rbvfit/vfit_mcmc.py:291-353
+ * evaluated for a whole batch of walkers per call on one MI355X (gfx950).
+ *
+ * The reference is pure Python, so "the reference's FFI for this path" is a ctypes binding;
+ * INTEGRATION.md shows the stub a maintainer would add.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a non-zero VP_E* code otherwise; the text of the
+ *     last failure is available from vp_last_error().  Errors are never signalled through the
+ *     numeric outputs.
+ *   - numeric conventions INSIDE outputs follow the reference: a theta row outside [lb,ub] gets
+ *     lnprob = -inf and its model is not evaluated (vfit_mcmc.py:291-295,348-353); NaN produced
+ *     by the arithmetic (e.g. error == 0) propagates as NaN.
+ *   - all arrays are C-contiguous; "host" pointers are ordinary process memory owned by the
+ *     caller and only read/written during the call; "device" pointers are HIP device memory on
+ *     the context's GPU.
+ *   - the library copies everything passed to vp_set_bounds / vp_add_instrument.
+ *   - a context may be used from any thread, one call at a time (internal mutex); it is NOT
+ *     fork-safe (create it in the process that uses it; rbvfit callers pass use_pool=False).
+ */
+#ifndef RBVFIT_AMD_H
+#define RBVFIT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vp_ctx vp_ctx;
+
+enum {
+    VP_OK = 0,
+    VP_EINVAL = 1,      /* bad argument (shape, index out of range, NULL) */
+    VP_EHIP = 2,        /* a HIP runtime call failed */
+    VP_ESTATE = 3,      /* call order (e.g. lnprob before bounds/instruments are set) */
+    VP_ENOMEM = 4
+};
+
+/* LSF dispatch branches of core/voigt_model.py:220-230 */
+enum {
+    VP_LSF_NONE = 0,            /* kernel is None: no convolution                          (:221) */
+    VP_LSF_SCIPY_NEAREST = 1,   /* Gaussian1DKernel -> ndimage.convolve1d(mode='nearest')  (:224) */
+    VP_LSF_ASTROPY_EXTEND = 2   /* CustomKernel -> astropy convolve(boundary='extend'):
+                                   taps are divided by their sum                     (:227,230) */
+};
+
+/* voigt_method of VoigtModel (core/voigt_model.py:359-364) */
+enum { VP_VOIGT_WOFZ = 0, VP_VOIGT_FAST = 1 };
+
+/* Number of HIP devices visible to the process (0 if none / HIP unusable). */
+int vp_device_count(void);
+
+/* Create a context bound to one GPU.  Replaces: construction of `vfit` (vfit_mcmc.py:127-197). */
+int vp_ctx_create(vp_ctx** out, int device_id);
+int vp_ctx_destroy(vp_ctx* ctx);
+
+/* Box prior.  Replaces: vfit.lb / vfit.ub used by lnprior (vfit_mcmc.py:291-295).
+ * Fixes D = ndim for the context. */
+int vp_set_bounds(vp_ctx* ctx, int D, const double* lb, const double* ub);
+
+/* Add one instrument = one entry of vfit.instrument_data after _compile_models
+ * (vfit_mcmc.py:234-259) together with the CompiledModelData of its model
+ * (core/voigt_model.py:265-280).
+ *   P, wave/flux/inv_sigma2/log_inv_sigma2 : spectrum and precomputed weights (T4: computed by the
+ *       host in the dtype the reference would use, then widened to double)
+ *   L, lambda0/gamma/f/zfac                : per-line atomic_lambda0, atomic_gamma, atomic_f
+ *       (float32-rounded then widened, rb_setline.py:42,44) and z_factors
+ *   N_idx/b_idx/v_idx                      : theta indices per line (core/voigt_model.py:440-442)
+ *   K, taps                                : kernel.array (K odd); K = 0 or taps = NULL with
+ *                                            lsf_mode = VP_LSF_NONE means no LSF
+ * Returns the instrument's index in *inst_index (may be NULL). */
+int vp_add_instrument(vp_ctx* ctx, int P, const double* wave, const double* flux,
+                      const double* inv_sigma2, const double* log_inv_sigma2,
+                      int L, const double* lambda0, const double* gamma, const double* f,
+                      const double* zfac, const int32_t* N_idx, const int32_t* b_idx,
+                      const int32_t* v_idx, int K, const double* taps, int lsf_mode,
+                      int voigt_method, int* inst_index);
+
+/* Replace the observed flux / weights of an instrument (same P); tables and LSF unchanged. */
+int vp_update_spectrum(vp_ctx* ctx, int inst, const double* flux, const double* inv_sigma2,
+                       const double* log_inv_sigma2);
+
+/* lnprob for a batch of walkers.  Replaces: map(vfit.lnprob, theta_rows) (vfit_mcmc.py:348-353,
+ * the sampler fan-out of :408-440).  theta is row-major (W, D) host memory, out is (W,). */
+int vp_lnprob_batch(vp_ctx* ctx, int W, int D, const double* theta, double* out);
+
+/* Same, operands already resident on the context's GPU; enqueued on `hip_stream` (a hipStream_t,
+ * NULL = the context's own stream) and NOT synchronised: the caller orders later work on the
+ * same stream or synchronises it.  Successive calls on one context must be stream-ordered
+ * (they share the context's workspace). */
+int vp_lnprob_batch_device(vp_ctx* ctx, int W, int D, const double* d_theta, double* d_out,
+                           void* hip_stream);
+
+/* Model flux for a batch.  Replaces: CompiledVoigtModel.model_flux per row
+ * (core/voigt_model.py:295-311).  out is row-major (W, P) host memory.  convolved = 0 returns the
+ * profile before the LSF (VoigtModel.evaluate(return_unconvolved=True), :509-558).  The prior is
+ * not consulted (model_flux has none). */
+int vp_model_flux_batch(vp_ctx* ctx, int inst, int W, int D, const double* theta, double* out,
+                        int convolved);
+int vp_model_flux_batch_device(vp_ctx* ctx, int inst, int W, int D, const double* d_theta,
+                               double* d_out, int convolved, void* hip_stream);
+
+/* H(a_i, x_j) = Re w(x_j + i a_i) on the device for a grid (host buffers; out is row-major
+ * (na, nx)).  Test hook for the Faddeeva tiers that replace scipy.special.wofz at the call site
+ * core/voigt_model.py:156: the production tier logic is used (tier chosen per wavefront = 64
+ * consecutive x_j of one a_i). */
+int vp_voigt_h(vp_ctx* ctx, int na, const double* a, int nx, const double* x, double* out);
+
+/* Introspection */
+int vp_num_instruments(const vp_ctx* ctx);
+int vp_ndim(const vp_ctx* ctx);
+int vp_instrument_pixels(const vp_ctx* ctx, int inst);
+int vp_device_id(const vp_ctx* ctx);
+
+/* Text of the last error on this context (or of the last failed vp_ctx_create when ctx is NULL).
+ * Valid until the next call on the same context/thread. */
+const char* vp_last_error(const vp_ctx* ctx);
+
+/* Library version string, e.g. "rbvfit_amd 0.1.0 (gfx950)". */
+const char* vp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBVFIT_AMD_H */

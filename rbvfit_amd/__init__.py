@@ -1,0 +1,9 @@
+"""rbvfit_amd -- MI355X-native Voigt forward model + log-likelihood engine behind rbvfit's
+``CompiledVoigtModel.model_flux`` / ``vfit.lnprob`` interface.  See DESIGN.md."""
+from ._lib import (RbvfitAmdError, RbvfitAmdLibraryError, LSF_NONE, LSF_SCIPY_NEAREST,
+                   LSF_ASTROPY_EXTEND, VOIGT_WOFZ, VOIGT_FAST, LIB_PATH)
+from .engine import Engine, device_count
+
+__version__ = "0.1.0"
+__all__ = ["Engine", "device_count", "RbvfitAmdError", "RbvfitAmdLibraryError", "LIB_PATH",
+           "LSF_NONE", "LSF_SCIPY_NEAREST", "LSF_ASTROPY_EXTEND", "VOIGT_WOFZ", "VOIGT_FAST"]

@@ -1,0 +1,87 @@
+"""ctypes binding of librbvfit_amd.so (the C ABI declared in include/rbvfit_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or cannot be loaded the import
+of the product path fails loudly (``RbvfitAmdLibraryError``).  Nothing under ``oracle/`` is ever
+imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librbvfit_amd.so")
+
+VP_OK, VP_EINVAL, VP_EHIP, VP_ESTATE, VP_ENOMEM = 0, 1, 2, 3, 4
+LSF_NONE, LSF_SCIPY_NEAREST, LSF_ASTROPY_EXTEND = 0, 1, 2
+VOIGT_WOFZ, VOIGT_FAST = 0, 1
+
+
+class RbvfitAmdLibraryError(ImportError):
+    pass
+
+
+class RbvfitAmdError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rbvfit_amd error {code}: {message}")
+        self.code = code
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/rbvfit_amd.h
+SIGNATURES = {
+    "vp_version": (C.c_char_p, []),
+    "vp_device_count": (C.c_int, []),
+    "vp_ctx_create": (C.c_int, [C.POINTER(_ctx), C.c_int]),
+    "vp_ctx_destroy": (C.c_int, [_ctx]),
+    "vp_set_bounds": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
+    "vp_add_instrument": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp,
+                                    _ip, _ip, _ip, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "vp_update_spectrum": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),
+    "vp_lnprob_batch": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp]),
+    "vp_lnprob_batch_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vp_model_flux_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int]),
+    "vp_model_flux_batch_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_void_p]),
+    "vp_voigt_h": (C.c_int, [_ctx, C.c_int, _dp, C.c_int, _dp, _dp]),
+    "vp_num_instruments": (C.c_int, [_ctx]),
+    "vp_ndim": (C.c_int, [_ctx]),
+    "vp_instrument_pixels": (C.c_int, [_ctx, C.c_int]),
+    "vp_device_id": (C.c_int, [_ctx]),
+    "vp_last_error": (C.c_char_p, [_ctx]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise RbvfitAmdLibraryError if it is absent/unloadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RbvfitAmdLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  rbvfit_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise RbvfitAmdLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RbvfitAmdLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc):
+    if rc != VP_OK:
+        msg = lib.vp_last_error(ctx)
+        raise RbvfitAmdError(rc, msg.decode() if msg else "unknown error")

@@ -1,0 +1,437 @@
+// C ABI of the rbvfit_amd engine (see include/rbvfit_amd.h).  Host side: context, device
+// residency of the static data, workspace, launches.  No torch types, no Python.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rbvfit_amd.h"
+#include "voigt_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Instrument {
+    vp::InstDev dev{};
+    vp::LinesDev lines{};
+    double sum_logw = 0.0;
+    std::vector<void*> allocs;   // device allocations owned by this instrument
+    double* d_flux = nullptr;
+    double* d_w = nullptr;
+    size_t lds_bytes = 0;
+};
+
+}  // namespace
+
+struct vp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    mutable std::string err;
+    int D = 0;
+    double* d_lb = nullptr;
+    double* d_ub = nullptr;
+    std::vector<Instrument> inst;
+    // per-batch workspace (grown on demand)
+    int capW = 0;
+    int capL = 0;          // max lines over instruments the workspace was sized for
+    int cap_tiles = 0;
+    double* d_theta = nullptr;   // (capW, D)
+    double* d_out = nullptr;     // (capW)
+    double* d_lc = nullptr;      // (capW, capL, LC_STRIDE)
+    double* d_partial = nullptr; // (capW, total_tiles)
+    int* d_flags = nullptr;      // (capW)
+    int* d_tile_off = nullptr;   // (n_inst + 1)
+    double* d_sum_logw = nullptr;
+    bool meta_dirty = true;
+    int total_tiles = 0;
+    double* h_pinned = nullptr;  // staging for theta / out
+    size_t h_pinned_bytes = 0;
+    // model_flux / voigt_h scratch
+    double* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+namespace {
+
+int fail(const vp_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail((c), VP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+
+template <class T>
+int upload(vp_ctx* c, Instrument* ins, const T* host, size_t n, T** out) {
+    T* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, (n ? n : 1) * sizeof(T)));
+    if (ins) ins->allocs.push_back(d);
+    if (n) HIP_TRY(c, hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return VP_OK;
+}
+
+double neumaier_sum(const double* v, int n) {
+    double s = 0.0, comp = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double t = s + v[i];
+        if (std::fabs(s) >= std::fabs(v[i])) comp += (s - t) + v[i]; else comp += (v[i] - t) + s;
+        s = t;
+    }
+    return s + comp;
+}
+
+int ensure_scratch(vp_ctx* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return VP_OK;
+    if (c->d_scratch) HIP_TRY(c, hipFree(c->d_scratch));
+    c->d_scratch = nullptr; c->scratch_bytes = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_scratch, bytes));
+    c->scratch_bytes = bytes;
+    return VP_OK;
+}
+
+int ensure_pinned(vp_ctx* c, size_t bytes) {
+    if (bytes <= c->h_pinned_bytes) return VP_OK;
+    if (c->h_pinned) HIP_TRY(c, hipHostFree(c->h_pinned));
+    c->h_pinned = nullptr; c->h_pinned_bytes = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, bytes, hipHostMallocDefault));
+    c->h_pinned_bytes = bytes;
+    return VP_OK;
+}
+
+int ensure_workspace(vp_ctx* c, int W) {
+    int maxL = 1;
+    for (auto& in : c->inst) maxL = std::max(maxL, in.dev.L);
+    if (c->meta_dirty) {
+        std::vector<int> off(c->inst.size() + 1, 0);
+        std::vector<double> slw(c->inst.size() + 1, 0.0);
+        for (size_t k = 0; k < c->inst.size(); ++k) {
+            off[k + 1] = off[k] + c->inst[k].dev.ntiles;
+            slw[k] = c->inst[k].sum_logw;
+        }
+        c->total_tiles = off.back();
+        if (c->d_tile_off) HIP_TRY(c, hipFree(c->d_tile_off));
+        if (c->d_sum_logw) HIP_TRY(c, hipFree(c->d_sum_logw));
+        HIP_TRY(c, hipMalloc((void**)&c->d_tile_off, off.size() * sizeof(int)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_sum_logw, slw.size() * sizeof(double)));
+        HIP_TRY(c, hipMemcpy(c->d_tile_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_sum_logw, slw.data(), slw.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->meta_dirty = false;
+    }
+    if (W <= c->capW && maxL <= c->capL && c->total_tiles <= c->cap_tiles) return VP_OK;
+    // a stream-ordered previous call may still be using the old buffers
+    HIP_TRY(c, hipDeviceSynchronize());
+    const int newW = std::max(W, c->capW);
+    for (void* p : {(void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial, (void*)c->d_flags})
+        if (p) HIP_TRY(c, hipFree(p));
+    c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->capW = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_theta, (size_t)newW * std::max(c->D, 1) * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_out, (size_t)newW * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_lc, (size_t)newW * maxL * vp::LC_STRIDE * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_partial, (size_t)newW * std::max(c->total_tiles, 1) * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_flags, (size_t)newW * sizeof(int)));
+    HIP_TRY(c, hipMemset(c->d_flags, 0, (size_t)newW * sizeof(int)));
+    c->capW = newW; c->capL = maxL; c->cap_tiles = c->total_tiles;
+    return VP_OK;
+}
+
+template <int OUT>
+void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
+                 int W, hipStream_t s) {
+    dim3 grid(in.dev.ntiles, W);
+    if (in.dev.method == VP_VOIGT_FAST)
+        hipLaunchKernelGGL((vp::tile_kernel<1, OUT>), grid, dim3(vp::TILE_THREADS), in.lds_bytes, s, in.dev, lc, flags,
+                           out, stride, offset);
+    else
+        hipLaunchKernelGGL((vp::tile_kernel<0, OUT>), grid, dim3(vp::TILE_THREADS), in.lds_bytes, s, in.dev, lc, flags,
+                           out, stride, offset);
+}
+
+// enqueue the whole lnprob pipeline for device-resident theta / out
+int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
+    int tile_off = 0;
+    for (size_t k = 0; k < c->inst.size(); ++k) {
+        const Instrument& in = c->inst[k];
+        hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines,
+                           c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0);
+        launch_tile<0>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s);
+        tile_off += in.dev.ntiles;
+    }
+    hipLaunchKernelGGL(vp::finalize_kernel, dim3((W + 255) / 256), dim3(256), 0, s, c->d_partial, c->total_tiles,
+                       c->d_tile_off, c->d_sum_logw, (int)c->inst.size(), c->d_flags, d_out, W);
+    HIP_TRY(c, hipGetLastError());
+    return VP_OK;
+}
+
+int check_batch_args(vp_ctx* c, int W, int D, const void* a, const void* b) {
+    if (!c) return VP_EINVAL;
+    if (c->D <= 0) return fail(c, VP_ESTATE, "vp_set_bounds has not been called");
+    if (c->inst.empty()) return fail(c, VP_ESTATE, "no instrument has been added");
+    if (D != c->D) return fail(c, VP_EINVAL, "theta has D=" + std::to_string(D) + " but the context was set up with D=" + std::to_string(c->D));
+    if (W < 0) return fail(c, VP_EINVAL, "negative batch size");
+    if (W > 0 && (!a || !b)) return fail(c, VP_EINVAL, "NULL theta/out");
+    return VP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vp_version(void) { return "rbvfit_amd 0.1.0 (gfx950, hip)"; }
+
+int vp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* vp_last_error(const vp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int vp_ctx_create(vp_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, VP_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, VP_EHIP, std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, VP_EINVAL, "device_id out of range");
+    vp_ctx* c = new (std::nothrow) vp_ctx();
+    if (!c) return fail(nullptr, VP_ENOMEM, "out of host memory");
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        std::string m = std::string("context creation failed: ") + hipGetErrorString(e);
+        delete c;
+        return fail(nullptr, VP_EHIP, m);
+    }
+    *out = c;
+    return VP_OK;
+}
+
+int vp_ctx_destroy(vp_ctx* c) {
+    if (!c) return VP_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& in : c->inst) for (void* p : in.allocs) hipFree(p);
+    for (void* p : {(void*)c->d_lb, (void*)c->d_ub, (void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial,
+                    (void*)c->d_flags, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch})
+        if (p) hipFree(p);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return VP_OK;
+}
+
+int vp_set_bounds(vp_ctx* c, int D, const double* lb, const double* ub) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (D <= 0 || !lb || !ub) return fail(c, VP_EINVAL, "vp_set_bounds: D must be positive and lb/ub non-NULL");
+    if (!c->inst.empty() && D != c->D) return fail(c, VP_ESTATE, "vp_set_bounds: D differs from the D the instruments were validated against");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (c->d_lb) HIP_TRY(c, hipFree(c->d_lb));
+    if (c->d_ub) HIP_TRY(c, hipFree(c->d_ub));
+    c->d_lb = c->d_ub = nullptr;
+    int rc;
+    if ((rc = upload<double>(c, nullptr, lb, D, &c->d_lb))) return rc;
+    if ((rc = upload<double>(c, nullptr, ub, D, &c->d_ub))) return rc;
+    if (D != c->D) {   // drop the workspace, it is resized lazily
+        for (void* p : {(void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial, (void*)c->d_flags})
+            if (p) hipFree(p);
+        c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->capW = 0;
+    }
+    c->D = D;
+    return VP_OK;
+}
+
+int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, const double* inv_sigma2,
+                      const double* log_inv_sigma2, int L, const double* lambda0, const double* gamma,
+                      const double* f, const double* zfac, const int32_t* N_idx, const int32_t* b_idx,
+                      const int32_t* v_idx, int K, const double* taps, int lsf_mode, int voigt_method,
+                      int* inst_index) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->D <= 0) return fail(c, VP_ESTATE, "vp_add_instrument: call vp_set_bounds first (theta indices are validated against D)");
+    if (P <= 0 || !wave || !flux || !inv_sigma2 || !log_inv_sigma2) return fail(c, VP_EINVAL, "vp_add_instrument: empty or NULL spectrum");
+    if (L <= 0 || !lambda0 || !gamma || !f || !zfac || !N_idx || !b_idx || !v_idx) return fail(c, VP_EINVAL, "vp_add_instrument: empty or NULL line tables");
+    if (voigt_method != VP_VOIGT_WOFZ && voigt_method != VP_VOIGT_FAST) return fail(c, VP_EINVAL, "vp_add_instrument: unknown voigt_method");
+    if (lsf_mode < VP_LSF_NONE || lsf_mode > VP_LSF_ASTROPY_EXTEND) return fail(c, VP_EINVAL, "vp_add_instrument: unknown lsf_mode");
+    if (lsf_mode != VP_LSF_NONE && (K <= 0 || !taps)) return fail(c, VP_EINVAL, "vp_add_instrument: lsf_mode set but no taps");
+    if (lsf_mode != VP_LSF_NONE && (K % 2) == 0) return fail(c, VP_EINVAL, "vp_add_instrument: the number of taps must be odd");
+    if (K > 2049) return fail(c, VP_EINVAL, "vp_add_instrument: more than 2049 LSF taps is not supported");
+    for (int l = 0; l < L; ++l) {
+        if (N_idx[l] < 0 || N_idx[l] >= c->D || b_idx[l] < 0 || b_idx[l] >= c->D || v_idx[l] < 0 || v_idx[l] >= c->D)
+            return fail(c, VP_EINVAL, "vp_add_instrument: theta index of line " + std::to_string(l) + " outside [0, D)");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    Instrument in;
+    int rc;
+    // flipped (and, for the astropy branch, normalised) taps: out[p] = sum_j kflip[j] f[p - halo_lo + j]
+    std::vector<double> kflip;
+    int Kuse = 1, cidx = 0;
+    if (lsf_mode == VP_LSF_NONE) {
+        kflip.assign(1, 1.0);
+    } else {
+        Kuse = K; cidx = K / 2;
+        double norm = 1.0;
+        if (lsf_mode == VP_LSF_ASTROPY_EXTEND) { norm = 0.0; for (int j = 0; j < K; ++j) norm += taps[j]; }
+        kflip.resize(K);
+        for (int j = 0; j < K; ++j) {
+            double t = taps[K - 1 - j];
+            kflip[j] = (lsf_mode == VP_LSF_ASTROPY_EXTEND) ? t / norm : t;
+        }
+    }
+    std::vector<double> ginv(P);
+    for (int p = 0; p < P; ++p) ginv[p] = 1.0 / wave[p];
+    double *d_wave, *d_ginv, *d_flux, *d_w, *d_k, *d_l0, *d_g, *d_f, *d_z;
+    int *d_n, *d_b, *d_v;
+#define UP(T, h, n, d) if ((rc = upload<T>(c, &in, h, n, &d))) { for (void* p : in.allocs) hipFree(p); return rc; }
+    UP(double, wave, P, d_wave) UP(double, ginv.data(), P, d_ginv) UP(double, flux, P, d_flux) UP(double, inv_sigma2, P, d_w)
+    UP(double, kflip.data(), kflip.size(), d_k)
+    UP(double, lambda0, L, d_l0) UP(double, gamma, L, d_g) UP(double, f, L, d_f) UP(double, zfac, L, d_z)
+    UP(int, N_idx, L, d_n) UP(int, b_idx, L, d_b) UP(int, v_idx, L, d_v)
+#undef UP
+    in.d_flux = d_flux; in.d_w = d_w;
+    in.lines = vp::LinesDev{L, d_l0, d_g, d_f, d_z, d_n, d_b, d_v};
+    vp::InstDev& d = in.dev;
+    d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method;
+    int span = 1024;
+    if (Kuse > 257) span = std::min(8192, ((4 * Kuse + 63) / 64) * 64);
+    const int need = P + Kuse - 1;
+    if (need < span) span = ((need + 63) / 64) * 64;
+    d.span = span; d.TP = span - (Kuse - 1);
+    d.ntiles = (P + d.TP - 1) / d.TP;
+    d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
+    in.lds_bytes = (size_t)(span + 4) * sizeof(double);
+    in.sum_logw = neumaier_sum(log_inv_sigma2, P);
+    c->inst.push_back(std::move(in));
+    c->meta_dirty = true;
+    if (inst_index) *inst_index = (int)c->inst.size() - 1;
+    return VP_OK;
+}
+
+int vp_update_spectrum(vp_ctx* c, int inst, const double* flux, const double* inv_sigma2, const double* log_inv_sigma2) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_update_spectrum: instrument index out of range");
+    if (!flux || !inv_sigma2 || !log_inv_sigma2) return fail(c, VP_EINVAL, "vp_update_spectrum: NULL array");
+    Instrument& in = c->inst[inst];
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(in.d_flux, flux, (size_t)in.dev.P * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(in.d_w, inv_sigma2, (size_t)in.dev.P * sizeof(double), hipMemcpyHostToDevice));
+    in.sum_logw = neumaier_sum(log_inv_sigma2, in.dev.P);
+    c->meta_dirty = true;
+    return VP_OK;
+}
+
+int vp_lnprob_batch_device(vp_ctx* c, int W, int D, const double* d_theta, double* d_out, void* hip_stream) {
+    int rc = check_batch_args(c, W, D, d_theta, d_out);
+    if (rc) return rc;
+    if (W == 0) return VP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, W))) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return enqueue_lnprob(c, W, d_theta, d_out, s);
+}
+
+int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
+    int rc = check_batch_args(c, W, D, theta, out);
+    if (rc) return rc;
+    if (W == 0) return VP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, W))) return rc;
+    const size_t tb = (size_t)W * D * sizeof(double), ob = (size_t)W * sizeof(double);
+    if ((rc = ensure_pinned(c, tb + ob))) return rc;
+    std::memcpy(c->h_pinned, theta, tb);
+    double* h_out = c->h_pinned + (size_t)W * D;
+    HIP_TRY(c, hipMemcpyAsync(c->d_theta, c->h_pinned, tb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = enqueue_lnprob(c, W, c->d_theta, c->d_out, c->stream))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out, h_out, ob);
+    return VP_OK;
+}
+
+int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* d_theta, double* d_out, int convolved,
+                               void* hip_stream) {
+    int rc = check_batch_args(c, W, D, d_theta, d_out);
+    if (rc) return rc;
+    if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_batch: instrument index out of range");
+    if (W == 0) return VP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, W))) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const Instrument& in = c->inst[inst];
+    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines, c->d_lb,
+                       c->d_ub, c->d_lc, c->d_flags, 0);
+    if (convolved) launch_tile<1>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s);
+    else launch_tile<2>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s);
+    HIP_TRY(c, hipGetLastError());
+    return VP_OK;
+}
+
+int vp_model_flux_batch(vp_ctx* c, int inst, int W, int D, const double* theta, double* out, int convolved) {
+    int rc = check_batch_args(c, W, D, theta, out);
+    if (rc) return rc;
+    if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_batch: instrument index out of range");
+    if (W == 0) return VP_OK;
+    size_t P;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIP_TRY(c, hipSetDevice(c->device));
+        if ((rc = ensure_workspace(c, W))) return rc;
+        P = c->inst[inst].dev.P;
+        if ((rc = ensure_scratch(c, (size_t)W * P * sizeof(double)))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = vp_model_flux_batch_device(c, inst, W, D, c->d_theta, c->d_scratch, convolved, c->stream))) return rc;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, (size_t)W * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+int vp_voigt_h(vp_ctx* c, int na, const double* a, int nx, const double* x, double* out) {
+    if (!c) return VP_EINVAL;
+    if (na <= 0 || nx <= 0 || !a || !x || !out) return fail(c, VP_EINVAL, "vp_voigt_h: empty or NULL input");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t rec = (size_t)na * vp::LC_STRIDE, need = (rec + na + nx + (size_t)na * nx) * sizeof(double);
+    int rc;
+    if ((rc = ensure_scratch(c, need))) return rc;
+    double* d_rec = c->d_scratch;
+    double* d_a = d_rec + rec;
+    double* d_x = d_a + na;
+    double* d_o = d_x + nx;
+    HIP_TRY(c, hipMemcpyAsync(d_a, a, na * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_x, x, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(vp::prep_h_kernel, dim3(na), dim3(64), 0, c->stream, d_a, d_rec);
+    hipLaunchKernelGGL(vp::voigt_h_kernel, dim3((nx + 255) / 256, na), dim3(256), 0, c->stream, d_rec, d_x, nx, d_o);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, d_o, (size_t)na * nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+int vp_num_instruments(const vp_ctx* c) { return c ? (int)c->inst.size() : 0; }
+int vp_ndim(const vp_ctx* c) { return c ? c->D : 0; }
+int vp_instrument_pixels(const vp_ctx* c, int inst) {
+    if (!c || inst < 0 || inst >= (int)c->inst.size()) return -1;
+    return c->inst[inst].dev.P;
+}
+int vp_device_id(const vp_ctx* c) { return c ? c->device : -1; }
+
+}  // extern "C"

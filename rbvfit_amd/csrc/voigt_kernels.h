@@ -1,0 +1,299 @@
+// HIP kernels of the Voigt lnprob path for gfx950 (MI355X).
+//
+// Data flow of one lnprob batch (W walkers, one instrument; instruments are launched back to back
+// on one stream and combined by finalize_kernel):
+//
+//   prep_lines_kernel   grid W*L x 64 thr   theta row -> per-(walker,line) 512-B record (vp::LC_*)
+//                                           + box-prior flag per walker        (vfit_mcmc.py:291-295)
+//   tile_kernel         grid (tiles, W) x 256   one workgroup = one walker x one pixel tile:
+//                         tau(p) = sum_l tau_l(p)  (tiered H, voigt_device.h)  (voigt_model.py:207-214)
+//                         exp(-tau) -> LDS                                      (:217)
+//                         K-tap LSF from LDS, taps through scalar loads         (:220-230)
+//                         chi^2 term vs flux / inv_sigma2, wave+block reduce   (vfit_mcmc.py:309-311)
+//                         -> partial[w][tile]      (deterministic: no float atomics)
+//   finalize_kernel     grid ceil(W/256) x 256  sum partials in fixed order, add -0.5*(.. - sum log w),
+//                                           -inf for out-of-bounds walkers    (vfit_mcmc.py:348-353)
+//
+// HBM layout: spectra (wave, 1/wave, flux, inv_sigma2) are 4 dense fp64 arrays per instrument,
+// read coalesced (8 B/lane) once per (walker, tile) and shared by all walkers through L2/MALL;
+// line records are read wave-uniformly (scalar loads, SGPR operands), never through VGPRs.
+#pragma once
+#include "voigt_device.h"
+
+namespace vp {
+
+struct LinesDev {          // static per-instrument line tables (CompiledModelData, voigt_model.py:265-280)
+    int L;
+    const double* lambda0;
+    const double* gamma;
+    const double* f;
+    const double* zfac;
+    const int* N_idx;
+    const int* b_idx;
+    const int* v_idx;
+};
+
+struct InstDev {
+    int P;         // pixels
+    int L;         // lines
+    int K;         // taps (>= 1; K = 1 with tap 1.0 when there is no LSF)
+    int halo_lo;   // K-1-c : evaluated pixels before the first output pixel of a tile
+    int span;      // evaluated pixels per full tile (multiple of 64)
+    int TP;        // output pixels per tile = span - (K-1)
+    int ntiles;
+    int method;    // VP_VOIGT_*
+    const double* wave;
+    const double* ginv;    // RN(1/wave)
+    const double* flux;
+    const double* w;       // inv_sigma2
+    const double* kflip;   // taps flipped (and normalised for the astropy branch): out[p] = sum_j kflip[j] f[p-halo_lo+j]
+};
+
+// ---------------------------------------------------------------------------------------------
+// compile-time table of the wing-series polynomials  C_m(a^2) = sum_i WC[m][i] a^(2i)
+//   WC[m][i] = binom(2m+1, 2i+1) (-1)^i (2(m-i)-1)!! / 2^(m-i)
+// ---------------------------------------------------------------------------------------------
+struct WingTable { double c[NWING][NWING]; };
+constexpr WingTable make_wing_table() {
+    WingTable t{};
+    unsigned long long binom[2 * NWING + 2][2 * NWING + 2] = {};
+    for (int n = 0; n < 2 * NWING + 2; ++n) {
+        binom[n][0] = 1;
+        for (int k = 1; k <= n; ++k) binom[n][k] = binom[n - 1][k - 1] + (k <= n - 1 ? binom[n - 1][k] : 0);
+    }
+    double dfo2[NWING] = {};   // (2n-1)!!/2^n
+    dfo2[0] = 1.0;
+    for (int n = 1; n < NWING; ++n) dfo2[n] = dfo2[n - 1] * (double)(2 * n - 1) * 0.5;
+    for (int m = 0; m < NWING; ++m)
+        for (int i = 0; i <= m; ++i)
+            t.c[m][i] = (double)binom[2 * m + 1][2 * i + 1] * ((i & 1) ? -1.0 : 1.0) * dfo2[m - i];
+    return t;
+}
+__constant__ const WingTable g_wing = make_wing_table();
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Fill one record from (T, a) and, when given, the x-mapping scalars.  Called by all 64 lanes of a
+// wave; lane-parallel over table entries.
+__device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, double T, double a) {
+    int mode = 0;
+    if (!(a >= 0.0) || !(a < 7.0)) mode = 2;         // a < 0, a >= 7, NaN
+    else if (a > 0.1) mode = 1;
+    const double a2 = a * a;
+    // Gaussian-sum table and its plain sum
+    double tb = 0.0;
+    if (lane < NCORE) {
+        const double hn = ALG916_H * (double)(lane + 1);
+        const double hn2 = hn * hn;
+        tb = exp(-hn2) / (hn2 + a2);
+    }
+    const double S1 = wave_sum(tb);
+    if (lane < NCORE) rec[LC_TBL0 + lane] = (0.5 * ALG916_C * a) * tb;
+    // wing coefficients
+    if (lane < NWING) {
+        double cm = 0.0;
+        for (int i = lane; i >= 0; --i) cm = __builtin_fma(cm, a2, g_wing.c[lane][i]);
+        rec[LC_K0 + lane] = (T * (a * INV_SQRT_PI)) * cm;
+    }
+    if (lane == 0) {
+        rec[LC_T] = T;
+        rec[LC_Y] = a;
+        double ec = (mode == 2) ? 0.0 : erfcx(a);
+        rec[LC_ACOS] = ec - (ALG916_C * a) * S1;
+        reinterpret_cast<int*>(rec + LC_MODE)[0] = mode;
+        reinterpret_cast<int*>(rec + LC_MODE)[1] = 0;
+        rec[LC_BFAST] = 0.0;
+    }
+}
+
+// One 64-thread workgroup per (walker, line).  Follows _evaluate_compiled_model's scalar prologue
+// (voigt_model.py:192-200) and _vectorized_voigt_tau's per-line constants (:142-149) operation by
+// operation (the file is compiled with -ffp-contract=off, so nothing here is fused).
+__global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict__ theta, int W, int D,
+                                                        LinesDev T, const double* __restrict__ lb,
+                                                        const double* __restrict__ ub,
+                                                        double* __restrict__ lc, int* __restrict__ flags,
+                                                        int do_flags) {
+    const int w = blockIdx.x / T.L, l = blockIdx.x % T.L;
+    const int lane = threadIdx.x;
+    const double* th = theta + (size_t)w * D;
+    if (do_flags && l == 0) {
+        int oob = 0;
+        for (int d = lane; d < D; d += 64) oob |= (th[d] < lb[d]) || (th[d] > ub[d]);   // vfit_mcmc.py:293
+        const int any = __any(oob);
+        if (lane == 0) flags[w] = any ? 1 : 0;
+    }
+    double* rec = lc + ((size_t)w * T.L + l) * LC_STRIDE;
+    const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
+    const double N = pow(10.0, th[T.N_idx[l]]);        // :192
+    const double b = th[T.b_idx[l]];                   // :193
+    const double v = th[T.v_idx[l]];                   // :194
+    const double z_total = zf * (1.0 + v / C_KMS) - 1.0;   // :200
+    const double d = 1.0 + z_total;                    // :204
+    const double b_f = b / lam0 * 1e13;                // :142
+    const double freq0 = C_FREQ / lam0;                // :143
+    const double constant = ATOMIC_CONSTANT / (freq0 * b);   // :146
+    const double a = gam / (12.566370614359172 * b_f); // :149  (4*np.pi)
+    const double Tl = (N * fo) * constant;             // :158 (left-to-right)
+    fill_record(rec, lane, Tl, a);
+    if (lane == 0) {
+        const double cfd = C_FREQ * d;
+        rec[LC_A] = cfd / b_f;
+        rec[LC_B] = freq0 / b_f;
+        rec[LC_D] = d;
+        rec[LC_RD] = 1.0 / d;
+        rec[LC_CFD] = cfd;
+        rec[LC_FREQ0] = freq0;
+        rec[LC_IBF] = 1.0 / b_f;
+    }
+}
+
+// Test hook: records for a list of damping parameters with T = 1.
+__global__ __launch_bounds__(64) void prep_h_kernel(const double* __restrict__ a, double* __restrict__ lc) {
+    double* rec = lc + (size_t)blockIdx.x * LC_STRIDE;
+    fill_record(rec, threadIdx.x, 1.0, a[blockIdx.x]);
+    if (threadIdx.x == 0) {
+        rec[LC_A] = 0; rec[LC_B] = 0; rec[LC_D] = 1; rec[LC_RD] = 1; rec[LC_CFD] = 0; rec[LC_FREQ0] = 0; rec[LC_IBF] = 1;
+    }
+}
+
+struct PixelX {    // x of one pixel for one line, computed from the spectrum grid
+    double wv, g;
+    __device__ __forceinline__ double cheap(const double* __restrict__ rec) const {
+        return __builtin_fma(rec[LC_A], g, -rec[LC_B]);
+    }
+    __device__ __forceinline__ double faithful(const double* __restrict__ rec) const { return faithful_x(wv, g, rec); }
+};
+struct DirectX {   // x given (test hook)
+    double x;
+    __device__ __forceinline__ double cheap(const double* __restrict__) const { return x; }
+    __device__ __forceinline__ double faithful(const double* __restrict__) const { return x; }
+};
+
+#define VP_NONE_BELOW(xa, thr) (__ballot((xa) < (thr)) == 0ull)
+
+// Optical depth of one line at one pixel; tier chosen per wavefront from the cheap x.
+template <class XP>
+__device__ __forceinline__ double line_tau_wofz(const XP& xp, const double* __restrict__ rec) {
+    const int mode = reinterpret_cast<const int*>(rec + LC_MODE)[0];
+    const double xc = xp.cheap(rec);
+    const double xa = fabs(xc);
+    const double* __restrict__ K = rec + LC_K0;
+    if (mode == 0) {
+        if (VP_NONE_BELOW(xa, 100.0)) {            // far wings: the 1-FMA x is accurate enough
+            if (VP_NONE_BELOW(xa, 3000.0)) return wing_tau<2>(xc, K);
+            if (VP_NONE_BELOW(xa, 500.0)) return wing_tau<3>(xc, K);
+            return wing_tau<4>(xc, K);
+        }
+        const double xf = xp.faithful(rec);        // reproduce the reference's rounding of x
+        if (VP_NONE_BELOW(xa, 30.0)) return wing_tau<6>(xf, K);
+        if (VP_NONE_BELOW(xa, 14.0)) return wing_tau<9>(xf, K);
+        if (VP_NONE_BELOW(xa, 8.0)) return wing_tau<14>(xf, K);
+        const double T = rec[LC_T];
+        if (VP_NONE_BELOW(xa, X_CORE)) return __builtin_fma(T, exp(-xf * xf), wing_tau<NWING>(xf, K));
+        double r;
+        if (xa < X_CORE) r = T * core_H(xf, rec);
+        else r = __builtin_fma(T, exp(-xf * xf), wing_tau<NWING>(xf, K));
+        return r;
+    }
+    const double xf = xp.faithful(rec);
+    return rec[LC_T] * generic_H(xf, rec, mode);
+}
+
+template <class XP>
+__device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __restrict__ rec) {
+    const double xf = xp.faithful(rec);
+    return rec[LC_T] * tepper_garcia_H(xf, rec[LC_Y]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile kernel
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_THREADS = 256;
+
+template <int METHOD, int OUT>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
+__global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const double* __restrict__ lc,
+                                                            const int* __restrict__ flags,
+                                                            double* __restrict__ out, int out_stride,
+                                                            int out_offset) {
+    extern __shared__ double fl[];      // span doubles (+ 4 for the block reduce)
+    const int t = blockIdx.x, w = blockIdx.y;
+    if (OUT == 0 && flags[w]) return;   // out-of-bounds walker: likelihood is not evaluated
+    const int p0 = t * I.TP;
+    const int p1 = min(p0 + I.TP, I.P);
+    const int nout = p1 - p0;
+    const int n_eval = nout + I.K - 1;
+    const int q0 = p0 - I.halo_lo;
+    const double* __restrict__ lcw = lc + (size_t)w * I.L * LC_STRIDE;
+
+    for (int i = threadIdx.x; i < n_eval; i += TILE_THREADS) {
+        const int q = min(max(q0 + i, 0), I.P - 1);      // edge replication = evaluate the clamped pixel
+        PixelX xp{I.wave[q], I.ginv[q]};
+        double tau = 0.0;
+        for (int l = 0; l < I.L; ++l) {
+            const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
+            tau += (METHOD == 0) ? line_tau_wofz(xp, rec) : line_tau_fast(xp, rec);
+        }
+        fl[i] = exp(-tau);                                // voigt_model.py:217
+    }
+    __syncthreads();
+
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nout; i += TILE_THREADS) {
+        const int p = p0 + i;
+        double m;
+        if (OUT == 2) {
+            m = fl[i + I.halo_lo];
+        } else {
+            m = 0.0;
+            for (int j = 0; j < I.K; ++j) m = __builtin_fma(I.kflip[j], fl[i + j], m);
+        }
+        if (OUT == 0) {
+            const double r = I.flux[p] - m;
+            acc = __builtin_fma(r * r, I.w[p], acc);      // (flux-model)^2 * inv_sigma2
+        } else {
+            out[(size_t)w * out_stride + p] = m;
+        }
+    }
+    if (OUT == 0) {
+        acc = wave_sum(acc);
+        double* red = fl + I.span;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[(size_t)w * out_stride + out_offset + t] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// lnprob[w] = -inf if out of bounds else sum_inst -0.5 * (sum_tiles partial - sum log inv_sigma2)
+__global__ void finalize_kernel(const double* __restrict__ partial, int stride, const int* __restrict__ tile_off,
+                                const double* __restrict__ sum_logw, int n_inst,
+                                const int* __restrict__ flags, double* __restrict__ out, int W) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    if (flags[w]) { out[w] = -__builtin_inf(); return; }
+    const double* pw = partial + (size_t)w * stride;
+    double total = 0.0;
+    for (int k = 0; k < n_inst; ++k) {
+        double s = 0.0;
+        for (int t = tile_off[k]; t < tile_off[k + 1]; ++t) s += pw[t];
+        total += -0.5 * (s - sum_logw[k]);
+    }
+    out[w] = 0.0 + total;      // lp + lnlike (vfit_mcmc.py:353)
+}
+
+// Test hook: H(a_i, x_j) with the production tier logic (wave = 64 consecutive x_j of one a_i).
+__global__ __launch_bounds__(256) void voigt_h_kernel(const double* __restrict__ lc, const double* __restrict__ x,
+                                                      int nx, double* __restrict__ out) {
+    const double* __restrict__ rec = lc + (size_t)blockIdx.y * LC_STRIDE;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nx) return;
+    DirectX xp{x[j]};
+    out[(size_t)blockIdx.y * nx + j] = line_tau_wofz(xp, rec);
+}
+
+}  // namespace vp

@@ -1,0 +1,163 @@
+"""Thin object wrapper over the C ABI: one ``Engine`` = one ``vp_ctx`` on one MI355X.
+
+This is plumbing (array marshalling, lifetime, fork guard); all arithmetic happens in the HIP
+library.  Higher-level mirrors of the reference's interface live in ``rbvfit_amd.model`` and
+``rbvfit_amd.vfit``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def device_count() -> int:
+    return int(L.load().vp_device_count())
+
+
+class Engine:
+    """Context on one GPU.  Not fork-safe: the creating pid is recorded and any use from another
+    process raises (rbvfit's default ``use_pool=True`` forks; pass ``use_pool=False``)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = L.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.vp_ctx_create(C.byref(self._ctx), int(device_id))
+        if rc != L.VP_OK:
+            msg = self._lib.vp_last_error(None)
+            raise L.RbvfitAmdError(rc, msg.decode() if msg else "vp_ctx_create failed")
+        self._pid = os.getpid()
+        self.device_id = int(device_id)
+        self.ndim = 0
+        self.n_pixels = []
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value and os.getpid() == self._pid:
+            self._lib.vp_ctx_destroy(self._ctx)
+        self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _guard(self):
+        if os.getpid() != self._pid:
+            raise RuntimeError("rbvfit_amd.Engine used in a forked child: a HIP context does not survive "
+                               "fork(); create the engine in the process that uses it (use_pool=False)")
+        if not self._ctx.value:
+            raise RuntimeError("rbvfit_amd.Engine is closed")
+
+    def _check(self, rc):
+        L.check(self._lib, self._ctx, rc)
+
+    # -- setup ------------------------------------------------------------------------------
+    def set_bounds(self, lb, ub):
+        self._guard()
+        lb, ub = _f64(lb).ravel(), _f64(ub).ravel()
+        if lb.shape != ub.shape:
+            raise ValueError("lb and ub must have the same length")
+        self._check(self._lib.vp_set_bounds(self._ctx, lb.size, _dp(lb), _dp(ub)))
+        self.ndim = lb.size
+
+    def add_instrument(self, wave, flux, inv_sigma2, log_inv_sigma2, lambda0, gamma, f, zfac,
+                       N_idx, b_idx, v_idx, taps=None, lsf_mode=L.LSF_NONE, voigt_method=L.VOIGT_WOFZ) -> int:
+        self._guard()
+        wave, flux, w, lw = _f64(wave), _f64(flux), _f64(inv_sigma2), _f64(log_inv_sigma2)
+        if not (wave.ndim == 1 and wave.shape == flux.shape == w.shape == lw.shape):
+            raise ValueError("wave, flux, inv_sigma2 and log_inv_sigma2 must be 1-D arrays of equal length")
+        lam, gam, fo, zf = _f64(lambda0), _f64(gamma), _f64(f), _f64(zfac)
+        ni = np.ascontiguousarray(N_idx, dtype=np.int32)
+        bi = np.ascontiguousarray(b_idx, dtype=np.int32)
+        vi = np.ascontiguousarray(v_idx, dtype=np.int32)
+        if not (lam.shape == gam.shape == fo.shape == zf.shape == ni.shape == bi.shape == vi.shape):
+            raise ValueError("line tables must all have shape (n_lines,)")
+        if taps is None or lsf_mode == L.LSF_NONE or len(taps) == 0:
+            K, tp, lsf_mode = 0, None, L.LSF_NONE
+        else:
+            t = _f64(taps)
+            K, tp = t.size, _dp(t)
+        idx = C.c_int(-1)
+        self._check(self._lib.vp_add_instrument(
+            self._ctx, wave.size, _dp(wave), _dp(flux), _dp(w), _dp(lw), lam.size, _dp(lam), _dp(gam),
+            _dp(fo), _dp(zf), _ip(ni), _ip(bi), _ip(vi), K, tp, int(lsf_mode), int(voigt_method), C.byref(idx)))
+        self.n_pixels.append(wave.size)
+        return idx.value
+
+    def update_spectrum(self, inst, flux, inv_sigma2, log_inv_sigma2):
+        self._guard()
+        fl, w, lw = _f64(flux), _f64(inv_sigma2), _f64(log_inv_sigma2)
+        P = self.n_pixels[inst]
+        if not (fl.shape == w.shape == lw.shape == (P,)):
+            raise ValueError(f"arrays must have shape ({P},)")
+        self._check(self._lib.vp_update_spectrum(self._ctx, int(inst), _dp(fl), _dp(w), _dp(lw)))
+
+    # -- evaluation -------------------------------------------------------------------------
+    def _theta2d(self, theta):
+        th = _f64(theta)
+        if th.ndim == 1:
+            th = th[None, :]
+        if th.ndim != 2 or th.shape[1] != self.ndim:
+            raise ValueError(f"theta must have shape (W, {self.ndim}) or ({self.ndim},); got {np.shape(theta)}")
+        return th
+
+    def lnprob(self, theta) -> np.ndarray:
+        """(W, D) host array -> (W,) lnprob (H2D, kernels, D2H inside the call)."""
+        self._guard()
+        th = self._theta2d(theta)
+        out = np.empty(th.shape[0], dtype=np.float64)
+        self._check(self._lib.vp_lnprob_batch(self._ctx, th.shape[0], th.shape[1], _dp(th), _dp(out)))
+        return out
+
+    def lnprob_device(self, d_theta_ptr: int, d_out_ptr: int, W: int, stream_ptr: int = 0):
+        """Device-resident operands (raw pointers, e.g. ``tensor.data_ptr()``); asynchronous on
+        ``stream_ptr`` (a hipStream_t as int; 0 = the context's stream)."""
+        self._guard()
+        self._check(self._lib.vp_lnprob_batch_device(self._ctx, int(W), self.ndim, C.c_void_p(d_theta_ptr),
+                                                     C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr)))
+
+    def model_flux(self, inst: int, theta, convolved: bool = True) -> np.ndarray:
+        self._guard()
+        th = self._theta2d(theta)
+        out = np.empty((th.shape[0], self.n_pixels[inst]), dtype=np.float64)
+        self._check(self._lib.vp_model_flux_batch(self._ctx, int(inst), th.shape[0], th.shape[1], _dp(th),
+                                                  _dp(out), 1 if convolved else 0))
+        return out
+
+    def model_flux_device(self, inst: int, d_theta_ptr: int, d_out_ptr: int, W: int, convolved=True, stream_ptr=0):
+        self._guard()
+        self._check(self._lib.vp_model_flux_batch_device(self._ctx, int(inst), int(W), self.ndim,
+                                                         C.c_void_p(d_theta_ptr), C.c_void_p(d_out_ptr),
+                                                         1 if convolved else 0, C.c_void_p(stream_ptr)))
+
+    def voigt_h(self, a, x) -> np.ndarray:
+        """H(a_i, x_j) grid on the device (test hook for the Faddeeva tiers)."""
+        self._guard()
+        a, x = _f64(a).ravel(), _f64(x).ravel()
+        out = np.empty((a.size, x.size), dtype=np.float64)
+        self._check(self._lib.vp_voigt_h(self._ctx, a.size, _dp(a), x.size, _dp(x), _dp(out)))
+        return out
