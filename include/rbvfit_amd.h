@@ -114,6 +114,14 @@ int vp_model_flux_batch_device(vp_ctx* ctx, int inst, int W, int D, const double
  * consecutive x_j of one a_i). */
 int vp_voigt_h(vp_ctx* ctx, int na, const double* a, int nx, const double* x, double* out);
 
+/* Optional per-kernel timing with HIP events recorded on the stream the kernels are launched on
+ * (used by bench.py for the roofline figure).  While enabled, every lnprob batch records events
+ * around its prep / tile / finalize launches; vp_profile_read waits for them, returns the summed
+ * milliseconds per kernel kind and the number of tile-kernel launches, and clears the record. */
+int vp_profile_enable(vp_ctx* ctx, int enable);
+int vp_profile_read(vp_ctx* ctx, double* prep_ms, double* tile_ms, double* finalize_ms,
+                    int* n_tile_launches);
+
 /* Introspection */
 int vp_num_instruments(const vp_ctx* ctx);
 int vp_ndim(const vp_ctx* ctx);

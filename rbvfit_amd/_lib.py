@@ -47,6 +47,8 @@ SIGNATURES = {
     "vp_model_flux_batch_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]),
     "vp_voigt_h": (C.c_int, [_ctx, C.c_int, _dp, C.c_int, _dp, _dp]),
+    "vp_profile_enable": (C.c_int, [_ctx, C.c_int]),
+    "vp_profile_read": (C.c_int, [_ctx, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "vp_num_instruments": (C.c_int, [_ctx]),
     "vp_ndim": (C.c_int, [_ctx]),
     "vp_instrument_pixels": (C.c_int, [_ctx, C.c_int]),

@@ -55,6 +55,12 @@ struct vp_ctx {
     // model_flux / voigt_h scratch
     double* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Span { size_t a, b; int kind; };   // kind: 0 prep, 1 tile, 2 finalize
+    std::vector<Span> spans;
 };
 
 namespace {
@@ -157,18 +163,39 @@ void launch_tile(const Instrument& in, const double* lc, const int* flags, doubl
                            out, stride, offset);
 }
 
+size_t prof_mark(vp_ctx* c, hipStream_t s) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return (size_t)-1;
+        c->ev_pool.push_back(e);
+    }
+    const size_t i = c->ev_used++;
+    (void)hipEventRecord(c->ev_pool[i], s);
+    return i;
+}
+
 // enqueue the whole lnprob pipeline for device-resident theta / out
 int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
     int tile_off = 0;
+    const bool prof = c->profiling;
+    size_t m0 = prof ? prof_mark(c, s) : 0;
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines,
                            c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0);
+        size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s);
+        if (prof) {
+            size_t m2 = prof_mark(c, s);
+            c->spans.push_back({m0, m1, 0});
+            c->spans.push_back({m1, m2, 1});
+            m0 = m2;
+        }
         tile_off += in.dev.ntiles;
     }
     hipLaunchKernelGGL(vp::finalize_kernel, dim3((W + 255) / 256), dim3(256), 0, s, c->d_partial, c->total_tiles,
                        c->d_tile_off, c->d_sum_logw, (int)c->inst.size(), c->d_flags, d_out, W);
+    if (prof) { size_t m3 = prof_mark(c, s); c->spans.push_back({m0, m3, 2}); }
     HIP_TRY(c, hipGetLastError());
     return VP_OK;
 }
@@ -226,6 +253,7 @@ int vp_ctx_destroy(vp_ctx* c) {
                     (void*)c->d_flags, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch})
         if (p) hipFree(p);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VP_OK;
@@ -423,6 +451,38 @@ int vp_voigt_h(vp_ctx* c, int na, const double* a, int nx, const double* x, doub
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, d_o, (size_t)na * nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+int vp_profile_enable(vp_ctx* c, int enable) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->profiling = enable != 0;
+    c->ev_used = 0;
+    c->spans.clear();
+    return VP_OK;
+}
+
+int vp_profile_read(vp_ctx* c, double* prep_ms, double* tile_ms, double* finalize_ms, int* n_tile_launches) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    double acc[3] = {0, 0, 0};
+    int ntile = 0;
+    for (const auto& sp : c->spans) {
+        if (sp.a == (size_t)-1 || sp.b == (size_t)-1) continue;
+        HIP_TRY(c, hipEventSynchronize(c->ev_pool[sp.b]));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[sp.a], c->ev_pool[sp.b]));
+        acc[sp.kind] += ms;
+        if (sp.kind == 1) ++ntile;
+    }
+    if (prep_ms) *prep_ms = acc[0];
+    if (tile_ms) *tile_ms = acc[1];
+    if (finalize_ms) *finalize_ms = acc[2];
+    if (n_tile_launches) *n_tile_launches = ntile;
+    c->ev_used = 0;
+    c->spans.clear();
     return VP_OK;
 }
 

@@ -161,3 +161,15 @@ class Engine:
         out = np.empty((a.size, x.size), dtype=np.float64)
         self._check(self._lib.vp_voigt_h(self._ctx, a.size, _dp(a), x.size, _dp(x), _dp(out)))
         return out
+
+    # -- per-kernel timing (HIP events on the launch stream) ------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._guard()
+        self._check(self._lib.vp_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self):
+        """-> dict(prep_ms, tile_ms, finalize_ms, n_tile_launches) summed since the last read."""
+        self._guard()
+        a, b, c_, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        self._check(self._lib.vp_profile_read(self._ctx, C.byref(a), C.byref(b), C.byref(c_), C.byref(n)))
+        return dict(prep_ms=a.value, tile_ms=b.value, finalize_ms=c_.value, n_tile_launches=n.value)

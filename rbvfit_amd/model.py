@@ -1,0 +1,223 @@
+"""Host-side mirror of the reference's model interface for the accelerated path.
+
+Mirrors (same names, argument meaning and error behaviour, reduced to what the path needs):
+  FitConfiguration.add_system            core/fit_configuration.py:318-351
+  VoigtModel(config, FWHM, voigt_method) core/voigt_model.py:334-384  (+ _cache_atomic_parameters
+                                         :386-412, _setup_fast_mapping :414-442, _setup_kernel :444-464)
+  VoigtModel.compile() -> CompiledVoigtModel.model_flux(theta, wavelength)   :466-507, :295-315
+  CompiledModelData                      :265-280 (astropy kernel object -> taps + lsf_mode)
+
+Everything here is setup; evaluation goes through ``rbvfit_amd.Engine`` (HIP).
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib as L
+from . import atomic
+from .engine import Engine
+from .lsf import gaussian_taps
+
+
+# ------------------------------------------------------------------------------------------------
+# physics description (minimal FitConfiguration)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class IonGroup:
+    ion_name: str
+    transitions: List[float]
+    components: int
+
+
+@dataclass
+class AbsorptionSystem:
+    redshift: float
+    ion_groups: List[IonGroup] = field(default_factory=list)
+
+
+class FitConfiguration:
+    """systems (z) -> ion groups (ion, transitions, components); theta layout is global
+    [N_0..N_{C-1} | b_0.. | v_0..] (core/voigt_model.py:440-442, parameter_manager.py:123-126)."""
+
+    def __init__(self, FWHM=None):
+        self.systems: List[AbsorptionSystem] = []
+        self.instrumental_params = {}
+        if FWHM is not None:
+            self.instrumental_params["FWHM"] = FWHM
+
+    def add_system(self, z: float, ion: str = "auto", transitions: Sequence[float] = None,
+                   components: int = 1) -> None:
+        if transitions is None:
+            raise ValueError("transitions list cannot be None")
+        if components < 1:
+            raise ValueError("components must be >= 1")
+        system = next((s for s in self.systems if s.redshift == z), None)
+        if system is None:
+            system = AbsorptionSystem(float(z))
+            self.systems.append(system)
+        if any(g.ion_name == ion for g in system.ion_groups):
+            raise ValueError(f"Ion {ion} already exists in system at z={z}")
+        # the reference snaps user wavelengths to the database values (fit_configuration.py:104-126, T13)
+        snapped = [float(atomic.lookup(w, "closest")["wave"]) for w in transitions]
+        system.ion_groups.append(IonGroup(str(ion), snapped, int(components)))
+
+    def validate(self) -> None:
+        if not self.systems:
+            raise ValueError("No absorption systems defined")
+
+    @property
+    def total_components(self) -> int:
+        return sum(g.components for s in self.systems for g in s.ion_groups)
+
+
+# ------------------------------------------------------------------------------------------------
+# compiled tables
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class CompiledModelData:
+    atomic_lambda0: np.ndarray
+    atomic_gamma: np.ndarray      # float32 like the reference (rb_setline.py:44)
+    atomic_f: np.ndarray          # float32 (rb_setline.py:42)
+    z_factors: np.ndarray
+    N_indices: np.ndarray
+    b_indices: np.ndarray
+    v_indices: np.ndarray
+    taps: Optional[np.ndarray]    # kernel.array of the reference's astropy kernel, or None
+    lsf_mode: int
+    n_lines: int
+    total_components: int
+    voigt_method: str = "wofz"
+
+    def engine_kwargs(self):
+        """Arguments of Engine.add_instrument after the table part (T1: float32 -> widened)."""
+        return dict(lambda0=np.asarray(self.atomic_lambda0, dtype=np.float64),
+                    gamma=np.asarray(self.atomic_gamma).astype(np.float64),
+                    f=np.asarray(self.atomic_f).astype(np.float64),
+                    zfac=np.asarray(self.z_factors, dtype=np.float64),
+                    N_idx=np.asarray(self.N_indices, dtype=np.int32),
+                    b_idx=np.asarray(self.b_indices, dtype=np.int32),
+                    v_idx=np.asarray(self.v_indices, dtype=np.int32),
+                    taps=self.taps, lsf_mode=self.lsf_mode,
+                    voigt_method=L.VOIGT_FAST if self.voigt_method == "fast" else L.VOIGT_WOFZ)
+
+
+def tables_from_rbvfit(compiled) -> CompiledModelData:
+    """Adapter for a *reference* ``CompiledVoigtModel`` (or its ``.data``): duck-typed, rbvfit and
+    astropy are not imported here.  Gaussian1DKernel -> scipy 'nearest' branch, any other kernel
+    object -> the astropy 'extend' (normalising) branch (core/voigt_model.py:220-230)."""
+    d = getattr(compiled, "data", compiled)
+    k = getattr(d, "kernel", None)
+    if k is None:
+        taps, mode = None, L.LSF_NONE
+    else:
+        taps = np.asarray(k.array, dtype=np.float64)
+        mode = L.LSF_SCIPY_NEAREST if type(k).__name__ == "Gaussian1DKernel" else L.LSF_ASTROPY_EXTEND
+    return CompiledModelData(np.asarray(d.atomic_lambda0), np.asarray(d.atomic_gamma), np.asarray(d.atomic_f),
+                             np.asarray(d.z_factors), np.asarray(d.N_indices), np.asarray(d.b_indices),
+                             np.asarray(d.v_indices), taps, mode, int(d.n_lines), int(d.total_components),
+                             getattr(d, "voigt_method", "wofz"))
+
+
+class VoigtModel:
+    """Single-instrument model description.  ``FWHM`` is in pixels, as a string or float, or None
+    for no LSF; ``kernel_taps`` supplies a tabulated LSF (the reference's 'COS' / CustomKernel
+    branch -> normalising 'extend' convolution).  ``normalize_kernel`` selects whether the Gaussian
+    taps are sum-normalised (astropy >= 5) or raw samples (astropy 4.x, the version the golden
+    fixtures were made with)."""
+
+    def __init__(self, config: FitConfiguration, FWHM: Union[str, float, None] = "6.5",
+                 voigt_method: str = "wofz", kernel_taps: Optional[Sequence[float]] = None,
+                 normalize_kernel: bool = False):
+        if voigt_method not in ("wofz", "fast"):
+            raise ValueError(f"voigt_method must be one of ('wofz', 'fast'), got '{voigt_method}'")
+        self.voigt_method = voigt_method
+        self.config = config
+        self.config.validate()
+        self.FWHM = config.instrumental_params.get("FWHM", FWHM)
+        if kernel_taps is not None:
+            self.taps, self.lsf_mode = np.asarray(kernel_taps, dtype=np.float64), L.LSF_ASTROPY_EXTEND
+        elif self.FWHM is None:
+            self.taps, self.lsf_mode = None, L.LSF_NONE
+        else:
+            self.taps = gaussian_taps(float(self.FWHM), normalize=normalize_kernel)
+            self.lsf_mode = L.LSF_SCIPY_NEAREST
+        # line order: system -> ion_group -> transition -> component   (voigt_model.py:391-401)
+        lam, gam, fv, zf, idx = [], [], [], [], []
+        offset = 0
+        for system in config.systems:
+            for g in system.ion_groups:
+                for wavelength in g.transitions:
+                    info = atomic.lookup(wavelength, "closest")
+                    for comp in range(g.components):
+                        lam.append(info["wave"]); gam.append(info["gamma"]); fv.append(info["fval"])
+                        zf.append(1.0 + system.redshift)
+                        idx.append(offset + comp)                # :428-437
+                offset += g.components
+        self.total_components = offset
+        self.n_lines = len(lam)
+        self.atomic_lambda0 = np.array(lam, dtype=np.float64)
+        self.atomic_gamma = np.array(gam, dtype=np.float32)
+        self.atomic_f = np.array(fv, dtype=np.float32)
+        self.z_factors = np.array(zf, dtype=np.float64)
+        self.N_indices = np.array(idx, dtype=np.int64)
+        self.b_indices = self.N_indices + self.total_components   # :441
+        self.v_indices = self.N_indices + 2 * self.total_components   # :442
+
+    def compile(self, verbose: bool = False, device_id: int = 0) -> "CompiledVoigtModel":
+        data = CompiledModelData(self.atomic_lambda0.copy(), self.atomic_gamma.copy(), self.atomic_f.copy(),
+                                 self.z_factors.copy(), self.N_indices.copy(), self.b_indices.copy(),
+                                 self.v_indices.copy(), None if self.taps is None else self.taps.copy(),
+                                 self.lsf_mode, self.n_lines, self.total_components, self.voigt_method)
+        if verbose:
+            print(f"Compiling VoigtModel: {3 * self.total_components} parameters, {self.n_lines} lines")
+        return CompiledVoigtModel(data, device_id)
+
+    def evaluate(self, theta, wavelength, return_unconvolved: bool = False):
+        """Analysis-time evaluation (core/voigt_model.py:509-558).  Note T10: the reference's
+        ``evaluate`` always uses the exact Voigt function, whatever ``voigt_method`` says."""
+        data = CompiledModelData(self.atomic_lambda0, self.atomic_gamma, self.atomic_f, self.z_factors,
+                                 self.N_indices, self.b_indices, self.v_indices, self.taps, self.lsf_mode,
+                                 self.n_lines, self.total_components, "wofz")
+        return CompiledVoigtModel(data).model_flux(theta, wavelength, convolved=not return_unconvolved)
+
+
+class CompiledVoigtModel:
+    """GPU-backed ``model_flux(theta, wavelength)``.  ``theta`` may be (D,) -> (P,) as in the
+    reference, or a batch (W, D) -> (W, P).  A model-only engine (unit weights) is cached per
+    wavelength grid.  Not picklable across processes by design (no fork Pool with HIP)."""
+
+    def __init__(self, data: CompiledModelData, device_id: int = 0):
+        self.data = data
+        self.device_id = device_id
+        self._engines = {}
+
+    def _engine_for(self, wavelength: np.ndarray) -> Engine:
+        wave = np.ascontiguousarray(wavelength, dtype=np.float64)
+        key = (wave.size, hashlib.blake2b(wave.tobytes(), digest_size=12).hexdigest())
+        eng = self._engines.get(key)
+        if eng is None:
+            D = 3 * self.data.total_components
+            eng = Engine(self.device_id)
+            eng.set_bounds(np.full(D, -np.inf), np.full(D, np.inf))
+            ones = np.ones_like(wave)
+            eng.add_instrument(wave, ones, ones, np.zeros_like(wave), **self.data.engine_kwargs())
+            if len(self._engines) >= 4:                      # small LRU: drop the oldest grid
+                self._engines.pop(next(iter(self._engines))).close()
+            self._engines[key] = eng
+        return eng
+
+    def model_flux(self, theta, wavelength, convolved: bool = True) -> np.ndarray:
+        theta = np.asarray(theta, dtype=np.float64)
+        out = self._engine_for(np.asarray(wavelength)).model_flux(0, theta, convolved=convolved)
+        return out[0] if theta.ndim == 1 else out
+
+    def __call__(self, theta, wavelength):
+        return self.model_flux(theta, wavelength)
+
+    def __getstate__(self):
+        raise TypeError("CompiledVoigtModel holds a GPU context and cannot be pickled; "
+                        "run the sampler with use_pool=False (batched lnprob replaces the Pool)")

@@ -1,0 +1,150 @@
+"""GPU-backed mirror of the reference's fitter for the posterior part only.
+
+Mirrors ``vfit.__init__`` (validation + _compile_models, vfit_mcmc.py:127-259), ``lnprior``
+(:291-295), ``lnlike`` (:297-319), ``lnprob`` (:348-353) and ``set_bounds`` (non-ion branch,
+:759-787).  The walker loop stays on the host (emcee/zeus with ``vectorize=True`` or
+``rbvfit_amd.sampler``); every call evaluates the whole theta batch in one GPU pass.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+from .engine import Engine
+from .model import CompiledModelData, CompiledVoigtModel, VoigtModel, tables_from_rbvfit
+
+
+def set_bounds(nguess, bguess, vguess, **kwargs):
+    """Traditional bounds of the reference (vfit_mcmc.py:759-787): N +/- 2, b -/+ 40 clipped to
+    [2, 150], v +/- 50; keyword overrides Nlow/blow/vlow/Nhi/bhi/vhi."""
+    nguess, bguess, vguess = (np.asarray(a, dtype=np.float64) for a in (nguess, bguess, vguess))
+    if kwargs.get("ions") is not None:
+        raise NotImplementedError("ion-aware bounds are outside the accelerated path (and broken in the "
+                                  "reference, SURVEY T16); pass explicit Nlow/Nhi/... overrides instead")
+    Nlow, NHI = nguess - 2.0, nguess + 2.0
+    blow, bHI = np.clip(bguess - 40.0, 2.0, None), np.clip(bguess + 40.0, None, 150.0)
+    vlow, vHI = vguess - 50.0, vguess + 50.0
+    Nlow = np.asarray(kwargs.get("Nlow", Nlow)); blow = np.asarray(kwargs.get("blow", blow))
+    vlow = np.asarray(kwargs.get("vlow", vlow)); NHI = np.asarray(kwargs.get("Nhi", NHI))
+    bHI = np.asarray(kwargs.get("bhi", bHI)); vHI = np.asarray(kwargs.get("vhi", vHI))
+    lb = np.concatenate([Nlow, blow, vlow])
+    ub = np.concatenate([NHI, bHI, vHI])
+    return [lb, ub], lb, ub
+
+
+def _tables_of(model) -> CompiledModelData:
+    if isinstance(model, CompiledModelData):
+        return model
+    if isinstance(model, CompiledVoigtModel):
+        return model.data
+    if isinstance(model, VoigtModel):
+        return model.compile().data
+    if hasattr(model, "config") and hasattr(model, "compile"):      # a reference rbvfit VoigtModel
+        return tables_from_rbvfit(model.compile(verbose=False))
+    if hasattr(model, "data") or hasattr(model, "atomic_lambda0"):  # reference CompiledVoigtModel / data
+        return tables_from_rbvfit(model)
+    raise TypeError("instrument 'model' must be a VoigtModel / CompiledVoigtModel / CompiledModelData "
+                    "(rbvfit_amd or rbvfit); arbitrary Python callables cannot run on the GPU")
+
+
+class vfit:
+    def __init__(self, instrument_data: Dict, theta, lb, ub, no_of_Chain=50, no_of_steps=1000,
+                 perturbation=1e-4, sampler="emcee", skip_initial_state_check=False, device_id: int = 0):
+        self._validate_unified_instrument_data(instrument_data)
+        self._validate_guesses(theta, lb, ub)
+        self.theta = np.asarray(theta, dtype=np.float64)
+        self.lb = np.asarray(lb, dtype=np.float64)
+        self.ub = np.asarray(ub, dtype=np.float64)
+        self.no_of_Chain = self.nwalkers = no_of_Chain
+        self.no_of_steps = no_of_steps
+        self.perturbation = perturbation
+        self.skip_initial_state_check = skip_initial_state_check
+        self.sampler_name = sampler.lower()
+        if self.sampler_name not in ("emcee", "zeus"):
+            raise ValueError(f"Unknown sampler '{sampler}'. Use 'emcee' or 'zeus'.")
+        self.ndim = len(self.theta)
+        self.multi_instrument = len(instrument_data) > 1
+        self.engine = Engine(device_id)
+        self.engine.set_bounds(self.lb, self.ub)
+        self.instrument_data = {}
+        for name, data in instrument_data.items():
+            tables = _tables_of(data["model"])
+            if 3 * tables.total_components != self.ndim:
+                raise ValueError(f"instrument '{name}': model has {3 * tables.total_components} parameters, "
+                                 f"theta has {self.ndim}")
+            error = np.asarray(data["error"])
+            entry = {
+                "tables": tables,
+                "wave": np.asarray(data["wave"]),
+                "flux": np.asarray(data["flux"]),
+                "error": error,
+                "inv_sigma2": 1.0 / (error ** 2),                  # vfit_mcmc.py:255 (dtype of error, T4)
+                "log_inv_sigma2": np.log(1.0 / (error ** 2)),      # :256
+            }
+            entry["index"] = self.engine.add_instrument(entry["wave"], entry["flux"], entry["inv_sigma2"],
+                                                        entry["log_inv_sigma2"], **tables.engine_kwargs())
+            self.instrument_data[name] = entry
+
+    # -- validation (vfit_mcmc.py:199-229) -----------------------------------------------------
+    @staticmethod
+    def _validate_unified_instrument_data(instrument_data):
+        if not isinstance(instrument_data, dict):
+            raise TypeError("instrument_data must be a dictionary")
+        if len(instrument_data) == 0:
+            raise ValueError("instrument_data cannot be empty")
+        required = {"model", "wave", "flux", "error"}
+        for name, data in instrument_data.items():
+            if not isinstance(data, dict):
+                raise TypeError(f"instrument_data['{name}'] must be a dictionary")
+            missing = required - set(data.keys())
+            if missing:
+                raise ValueError(f"instrument_data['{name}'] missing keys: {missing}")
+            n = len(data["wave"])
+            if len(data["flux"]) != n or len(data["error"]) != n:
+                raise ValueError(f"instrument_data['{name}']: wave, flux, and error must have same length")
+
+    @staticmethod
+    def _validate_guesses(theta, lb, ub):
+        theta, lb, ub = np.asarray(theta), np.asarray(lb), np.asarray(ub)
+        if len(theta) != len(lb) or len(theta) != len(ub):
+            raise ValueError("theta, lb, and ub must have the same length")
+        if np.any(theta < lb) or np.any(theta > ub):
+            raise ValueError("Initial guess theta must be within bounds lb and ub")
+
+    # -- posterior ----------------------------------------------------------------------------
+    def lnprior(self, theta):
+        """(D,) -> float or (W, D) -> (W,): 0 inside the box, -inf outside (bounds inclusive)."""
+        th = np.asarray(theta, dtype=np.float64)
+        oob = np.any(th < self.lb, axis=-1) | np.any(th > self.ub, axis=-1)
+        out = np.where(oob, -np.inf, 0.0)
+        return float(out) if th.ndim == 1 else out
+
+    def lnprob(self, theta):
+        """(D,) -> float, (W, D) -> (W,) float64: one GPU pass for the whole batch."""
+        th = np.asarray(theta, dtype=np.float64)
+        out = self.engine.lnprob(th)
+        return float(out[0]) if th.ndim == 1 else out
+
+    def lnlike(self, theta):
+        """Likelihood without the prior.  The engine fuses prior and likelihood; rows outside the
+        box are evaluated here through a context-free detour: lnlike = lnprob where the prior is 0,
+        and the model is evaluated explicitly for out-of-bounds rows."""
+        th = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+        out = self.engine.lnprob(th)
+        oob = np.isneginf(self.lnprior(th))
+        if np.any(oob):
+            out = out.copy()
+            rows = th[oob]
+            total = np.zeros(len(rows))
+            for entry in self.instrument_data.values():
+                model = self.engine.model_flux(entry["index"], rows)
+                total += -0.5 * np.sum((entry["flux"] - model) ** 2 * entry["inv_sigma2"]
+                                       - entry["log_inv_sigma2"], axis=1)
+            out[oob] = total
+        return float(out[0]) if np.asarray(theta).ndim == 1 else out
+
+    __call__ = lnprob
+
+    def close(self):
+        self.engine.close()
