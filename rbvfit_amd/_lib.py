@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librbvfit_amd.so")
+LIB_PATH = os.environ.get("RBVFIT_AMD_LIB") or os.path.join(_HERE, "lib", "librbvfit_amd.so")
 
 VP_OK, VP_EINVAL, VP_EHIP, VP_ESTATE, VP_ENOMEM = 0, 1, 2, 3, 4
 LSF_NONE, LSF_SCIPY_NEAREST, LSF_ASTROPY_EXTEND = 0, 1, 2

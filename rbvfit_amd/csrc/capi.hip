@@ -339,7 +339,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
-    in.lds_bytes = (size_t)(span + 4) * sizeof(double);
+    in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES) * sizeof(double);
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
     c->inst.push_back(std::move(in));
     c->meta_dirty = true;

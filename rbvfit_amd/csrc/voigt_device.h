@@ -6,17 +6,21 @@
 // pixels of one line), so the common case -- a line many Doppler widths away -- costs a handful
 // of FMAs instead of a special-function call:
 //
-//   |x| >= 6.5, a <= 0.1 : real asymptotic series  H = (a/sqrt(pi)) s sum_m C_m(a^2) s^m,
-//                          s = 1/x^2, C_m from the Gaussian moments of (t+ia)^(2m+1); the
-//                          per-line coefficients are premultiplied by N f constant a/sqrt(pi)
-//                          in the prep kernel, so a wing evaluation is one reciprocal + M FMAs
-//                          with M in {2,3,4,6,9,14,21} picked from the wave's smallest |x|.
-//   |x| <  6.5           : the exponentially convergent Gaussian-sum form of ACM TOMS Alg. 916
-//                          (Zaghloul & Ali 2011; the algorithm SciPy's Faddeeva package uses near
-//                          the real axis), with the per-line table exp(-h^2n^2)/(h^2n^2+a^2)
-//                          built once per (walker, line) by the prep kernel.
-//   a > 0.1 (unphysical for UV/optical absorbers, kept for API completeness): wings by the
-//                          Gautschi/Poppe-Wijers continued fraction in complex arithmetic.
+//   |x| >= 8, a <= 0.1 : real asymptotic series  H = (a/sqrt(pi)) s sum_m C_m(a^2) s^m,
+//                        s = 1/x^2, C_m from the Gaussian moments of (t+ia)^(2m+1); the
+//                        per-line coefficients are premultiplied by N f constant a/sqrt(pi)
+//                        in the prep kernel, so a wing evaluation is one reciprocal + M FMAs
+//                        with M in {2,3,4,6,9,14} picked from the wave's smallest |x|.
+//   |x| <  8, a <= 0.1 : Taylor series of w(z) in the damping direction about the real axis,
+//                          H = e^{a^2-x^2} cos(2ax) - a v_1 + a^3 v_3 - a^5 v_5 ...,
+//                          v_0 = (2/sqrt(pi)) F(x), v_1 = (2/sqrt(pi)) (1 - 2xF(x)),
+//                          v_{n+1} = -2 (x v_n + v_{n-1})/(n+1)     (from w' = -2zw + 2i/sqrt(pi)),
+//                        with the Dawson function F and G = 1-2xF from piecewise degree-13
+//                        polynomials (dawson_table.h); 1..7 odd terms depending on a.
+//   0.1 < a < 7 (unphysical for UV/optical absorbers, kept for API completeness): the Gaussian-sum
+//                        form of ACM TOMS Alg. 916 (Zaghloul & Ali 2011) near the axis, the
+//                        Gautschi/Poppe-Wijers continued fraction elsewhere; a >= 7: continued
+//                        fraction; a < 0: reflection formula.
 //
 // All approximations are held to <= ~1e-14 relative error in H (tests/test_faddeeva_gpu.py checks
 // 1e-12 against the golden scipy grid), which bounds the flux error by 0.37 * relerr.
@@ -24,11 +28,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dawson_table.h"
+
 namespace vp {
 
 // ---- per-(walker,line) record written by prep_lines_kernel, read with scalar loads ------------
 constexpr int LC_STRIDE = 64;   // doubles per record (512 B, one record = 4 x 128-B lines)
-constexpr int NWING = 21;       // longest wing series
+constexpr int NWING = 14;       // longest wing series (valid for |x| >= 8)
 constexpr int NCORE = 26;       // terms of the Gaussian sum (covers |x| < 7.2)
 enum {
     LC_A = 0,      // c_freq*(1+z_tot)/b_f           cheap x = fma(A, 1/wave, -B)
@@ -41,10 +47,11 @@ enum {
     LC_T = 7,      // (N*f)*constant
     LC_Y = 8,      // a = gamma/(4 pi b_f)
     LC_ACOS = 9,   // erfcx(a) - c*a*sum_n tbl_n
-    LC_MODE = 10,  // 0: a<=0.1 ; 1: 0.1<a<7 ; 2: a>=7 or a<0 or non-finite (generic path)
+    LC_MODE = 10,  // int[0]: 0: a<=0.1 ; 1: 0.1<a<7 ; 2: a>=7 or a<0 or non-finite (generic path)
+                   // int[1]: number of odd Taylor-in-a terms of the core series (mode 0)
     LC_K0 = 11,    // 21 wing coefficients  K_m = T*(a/sqrt(pi))*C_m(a^2)
     LC_TBL0 = 32,  // 26 entries  0.5*c*a*exp(-h^2 n^2)/(h^2 n^2 + a^2), n = 1..26
-    LC_BFAST = 58, // 'fast' method: eps threshold
+    LC_EA2 = 58,   // exp(a^2)
 };
 
 constexpr double C_FREQ = 2.99792458e18;          // core/voigt_model.py:130
@@ -53,7 +60,7 @@ constexpr double C_KMS = 299792.458;              // :197
 constexpr double ALG916_H = 0.518321480430085929872;   // step of the Gaussian sum
 constexpr double ALG916_C = 0.329973702884629072537;   // (2/pi) * h
 constexpr double INV_SQRT_PI = 0.56418958354775628694807945156;
-constexpr double X_CORE = 6.5;
+constexpr double X_CORE = 8.0;     // |x| below this: line-core evaluation
 
 // 1/d to full double precision without the IEEE division sequence (no scaling/fixup needed:
 // callers pass finite, normal, non-zero values; NaN/inf/0 propagate harmlessly).
@@ -94,8 +101,124 @@ __device__ __forceinline__ double wing_tau(double x, const double* __restrict__ 
     return acc * s;
 }
 
+// sin(t), cos(t) for |t| <= 1.5 by Taylor series (error < 1e-17): the core path only ever sees
+// t = |x| a <= 0.72 and 2t, so the library's full-range argument reduction is never needed.
+__device__ __forceinline__ double sinc_small(double t) {   // sin(t)/t
+    const double t2 = t * t;
+    double p = -8.2206352466243297e-18;               // -1/19!
+    p = __builtin_fma(p, t2, 2.8114572543455208e-15);   //  1/17!
+    p = __builtin_fma(p, t2, -7.6471637318198165e-13);  // -1/15!
+    p = __builtin_fma(p, t2, 1.6059043836821615e-10);   //  1/13!
+    p = __builtin_fma(p, t2, -2.5052108385441719e-08);  // -1/11!
+    p = __builtin_fma(p, t2, 2.7557319223985891e-06);   //  1/9!
+    p = __builtin_fma(p, t2, -1.9841269841269841e-04);  // -1/7!
+    p = __builtin_fma(p, t2, 8.3333333333333333e-03);   //  1/5!
+    p = __builtin_fma(p, t2, -1.6666666666666667e-01);  // -1/3!
+    return __builtin_fma(p, t2, 1.0);
+}
+__device__ __forceinline__ double cos_small(double t) {
+    const double t2 = t * t;
+    double p = 8.8967791632530450e-22;                 //  1/22!
+    p = __builtin_fma(p, t2, -4.1103176233121649e-19);  // -1/20!
+    p = __builtin_fma(p, t2, 1.5619206968586226e-16);   //  1/18!
+    p = __builtin_fma(p, t2, -4.7794773323873853e-14);  // -1/16!
+    p = __builtin_fma(p, t2, 1.1470745597729725e-11);   //  1/14!
+    p = __builtin_fma(p, t2, -2.0876756987868099e-09);  // -1/12!
+    p = __builtin_fma(p, t2, 2.7557319223985891e-07);   //  1/10!
+    p = __builtin_fma(p, t2, -2.4801587301587302e-05);  // -1/8!
+    p = __builtin_fma(p, t2, 1.3888888888888889e-03);   //  1/6!
+    p = __builtin_fma(p, t2, -4.1666666666666667e-02);  // -1/4!
+    p = __builtin_fma(p, t2, 0.5);
+    return __builtin_fma(-p, t2, 1.0);
+}
+
 __device__ __forceinline__ double sinc_safe(double t, double sint) {
     return fabs(t) < 1e-4 ? 1.0 - 0.1666666666666666666667 * t * t : sint / t;
+}
+
+// Number of odd terms (v_1, v_3, ...) of the core series needed for <= ~1e-15 relative error at
+// |x| < 8 (validated against 50-digit mpmath at the band edges, scripts/gen_dawson_table.py).
+__host__ __device__ __forceinline__ int core_terms(double a) {
+    return a <= 1e-9 ? 1 : a <= 5e-4 ? 2 : a <= 5e-3 ? 3 : a <= 2e-2 ? 4 : a <= 5e-2 ? 5 : 7;
+}
+
+// Core H(a,x) for |x| < 8, 0 <= a <= 0.1 (see the header comment).  `nodd` and `ea2` = exp(a^2)
+// are per-line constants.  Branch-free per lane; the only control flow is wave-uniform.
+__device__ __forceinline__ double core_taylor_H(double x, double a, double ea2, int nodd) {
+    const double ax = fabs(x);
+    const int i = min((int)(ax * 2.0), DAW_NI - 1);
+    const double t = __builtin_fma(ax, 4.0, -(double)(2 * i + 1));
+    const double* __restrict__ cf = &g_dawson[i][0][0];
+    double F = cf[DAW_DEG], G = cf[DAW_DEG + 1 + DAW_DEG];
+#pragma unroll
+    for (int k = DAW_DEG - 1; k >= 0; --k) {
+        F = __builtin_fma(F, t, cf[k]);
+        G = __builtin_fma(G, t, cf[DAW_DEG + 1 + k]);
+    }
+    const double c = 1.1283791670955125739;          // 2/sqrt(pi)
+    double vp = c * F, vc = c * G;                    // v_0, v_1
+    const double E = exp(-ax * ax);
+    const double a2 = a * a;
+    double apow = -a;                                 // (-1)^k a^(2k-1) with alternating sign folded in
+    double acc = apow * vc;
+    // -2/(n+1), -2/(n+2) for n = 1, 3, 5, ...
+    constexpr double R[12] = {-1.0, -2.0 / 3, -0.5, -0.4, -2.0 / 6, -2.0 / 7, -0.25, -2.0 / 9, -0.2, -2.0 / 11,
+                              -2.0 / 12, -2.0 / 13};
+#pragma unroll
+    for (int k = 1; k < 7; ++k) {
+        if (k < nodd) {                               // wave-uniform
+            const double v1 = R[2 * k - 2] * __builtin_fma(ax, vc, vp);
+            const double v2 = R[2 * k - 1] * __builtin_fma(ax, v1, vc);
+            vp = v1; vc = v2;
+            apow = -apow * a2;
+            acc = __builtin_fma(apow, vc, acc);
+        }
+    }
+    return __builtin_fma(E * ea2, cos_small(2.0 * a * ax), acc);
+}
+
+// Same series with the Dawson table staged in LDS as [interval][k][F,G] pairs (one ds_read_b128 per
+// degree); used by the tile kernel's hot loop.
+constexpr int DAW_LDS_DOUBLES = DAW_NI * 2 * (DAW_DEG + 1);
+__device__ __forceinline__ void dawson_to_lds(double* __restrict__ daw, int tid, int nthreads) {
+    for (int idx = tid; idx < DAW_LDS_DOUBLES; idx += nthreads) {
+        const int i = idx / (2 * (DAW_DEG + 1)), rem = idx % (2 * (DAW_DEG + 1));
+        daw[idx] = g_dawson[i][rem & 1][rem >> 1];
+    }
+}
+__device__ __forceinline__ double core_taylor_H_lds(double x, double a, double ea2, int nodd,
+                                                    const double* __restrict__ daw) {
+    const double ax = fabs(x);
+    const int i = min((int)(ax * 2.0), DAW_NI - 1);
+    const double t = __builtin_fma(ax, 4.0, -(double)(2 * i + 1));
+    const double2* __restrict__ cf = reinterpret_cast<const double2*>(daw) + i * (DAW_DEG + 1);
+    double2 ck = cf[DAW_DEG];
+    double F = ck.x, G = ck.y;
+#pragma unroll
+    for (int k = DAW_DEG - 1; k >= 0; --k) {
+        ck = cf[k];
+        F = __builtin_fma(F, t, ck.x);
+        G = __builtin_fma(G, t, ck.y);
+    }
+    const double c = 1.1283791670955125739;          // 2/sqrt(pi)
+    double vp = c * F, vc = c * G;                    // v_0, v_1
+    const double E = exp(-ax * ax);
+    const double a2 = a * a;
+    double apow = -a;
+    double acc = apow * vc;
+    constexpr double R[12] = {-1.0, -2.0 / 3, -0.5, -0.4, -2.0 / 6, -2.0 / 7, -0.25, -2.0 / 9, -0.2, -2.0 / 11,
+                              -2.0 / 12, -2.0 / 13};
+#pragma unroll
+    for (int k = 1; k < 7; ++k) {
+        if (k < nodd) {                               // wave-uniform
+            const double v1 = R[2 * k - 2] * __builtin_fma(ax, vc, vp);
+            const double v2 = R[2 * k - 1] * __builtin_fma(ax, v1, vc);
+            vp = v1; vc = v2;
+            apow = -apow * a2;
+            acc = __builtin_fma(apow, vc, acc);
+        }
+    }
+    return __builtin_fma(E * ea2, cos_small(2.0 * a * ax), acc);
 }
 
 // Core H(a,x), |x| < 7.2, 0 <= a < 7:  Alg. 916 real part
@@ -115,10 +238,10 @@ __device__ __forceinline__ double core_H(double x, const double* __restrict__ re
         s = __builtin_fma(rec[LC_TBL0 + n], p + q, s);
     }
     const double t = ax * y;
-    double sn, cs;
-    sn = sin(t);
-    cs = cos(2.0 * t);
-    const double head = __builtin_fma(rec[LC_ACOS], cs, (ALG916_C * ax) * sn * sinc_safe(t, sn));
+    double sn, sc, cs;
+    if (y <= 0.1) { sc = sinc_small(t); sn = sc * t; cs = cos_small(2.0 * t); }   // uniform per line
+    else { sn = sin(t); sc = sinc_safe(t, sn); cs = cos(2.0 * t); }
+    const double head = __builtin_fma(rec[LC_ACOS], cs, (ALG916_C * ax) * sn * sc);
     return E * (head + s);
 }
 

@@ -105,8 +105,8 @@ __device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, 
         double ec = (mode == 2) ? 0.0 : erfcx(a);
         rec[LC_ACOS] = ec - (ALG916_C * a) * S1;
         reinterpret_cast<int*>(rec + LC_MODE)[0] = mode;
-        reinterpret_cast<int*>(rec + LC_MODE)[1] = 0;
-        rec[LC_BFAST] = 0.0;
+        reinterpret_cast<int*>(rec + LC_MODE)[1] = core_terms(a);
+        rec[LC_EA2] = exp(a2);
     }
 }
 
@@ -177,6 +177,7 @@ struct DirectX {   // x given (test hook)
 #define VP_NONE_BELOW(xa, thr) (__ballot((xa) < (thr)) == 0ull)
 
 // Optical depth of one line at one pixel; tier chosen per wavefront from the cheap x.
+// (Single-chunk form: used by the H test hook and by the cold path of the tile kernel.)
 template <class XP>
 __device__ __forceinline__ double line_tau_wofz(const XP& xp, const double* __restrict__ rec) {
     const int mode = reinterpret_cast<const int*>(rec + LC_MODE)[0];
@@ -192,16 +193,75 @@ __device__ __forceinline__ double line_tau_wofz(const XP& xp, const double* __re
         const double xf = xp.faithful(rec);        // reproduce the reference's rounding of x
         if (VP_NONE_BELOW(xa, 30.0)) return wing_tau<6>(xf, K);
         if (VP_NONE_BELOW(xa, 14.0)) return wing_tau<9>(xf, K);
-        if (VP_NONE_BELOW(xa, 8.0)) return wing_tau<14>(xf, K);
-        const double T = rec[LC_T];
-        if (VP_NONE_BELOW(xa, X_CORE)) return __builtin_fma(T, exp(-xf * xf), wing_tau<NWING>(xf, K));
-        double r;
-        if (xa < X_CORE) r = T * core_H(xf, rec);
-        else r = __builtin_fma(T, exp(-xf * xf), wing_tau<NWING>(xf, K));
+        if (VP_NONE_BELOW(xa, X_CORE)) return wing_tau<NWING>(xf, K);
+        // line core: evaluated for every lane of the chunk (no divergence); lanes beyond the core
+        // radius of a mixed chunk take the 14-term wing value instead
+        const int nodd = reinterpret_cast<const int*>(rec + LC_MODE)[1];
+        double r = rec[LC_T] * core_taylor_H(xf, rec[LC_Y], rec[LC_EA2], nodd);
+        if (__ballot(xa >= X_CORE) != 0ull) {
+            const double rw = wing_tau<NWING>(xf, K);
+            r = (xa >= X_CORE) ? rw : r;
+        }
         return r;
     }
     const double xf = xp.faithful(rec);
     return rec[LC_T] * generic_H(xf, rec, mode);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A (walker,line) record held ACROSS THE LANES of one VGPR pair: lane k holds rec[k].  One
+// coalesced 512-B load per line and wave, prefetchable a line ahead; fields are pulled into SGPRs
+// with v_readlane (no scalar-memory round trips inside the line loop).
+// ---------------------------------------------------------------------------------------------
+struct LaneRec {
+    double v;
+    __device__ __forceinline__ double get(int k) const {      // k wave-uniform
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ int mode() const { return __builtin_amdgcn_readlane(__double2loint(v), LC_MODE); }
+    __device__ __forceinline__ int nodd() const { return __builtin_amdgcn_readlane(__double2hiint(v), LC_MODE); }
+};
+
+__device__ __forceinline__ double faithful_x(double wave, double g, const LaneRec& R) {
+    const double d = R.get(LC_D), rd = R.get(LC_RD), cfd = R.get(LC_CFD);
+    double q0 = wave * rd;
+    double e = __builtin_fma(-q0, d, wave);
+    double wr = __builtin_fma(e, rd, q0);
+    double f0 = cfd * g;
+    double y0 = d * g;
+    double e2 = __builtin_fma(-f0, wr, C_FREQ);
+    double freq = __builtin_fma(e2, y0, f0);
+    return (freq - R.get(LC_FREQ0)) * R.get(LC_IBF);
+}
+
+template <int M>
+__device__ __forceinline__ double wing_tau(double x, const LaneRec& R) {
+    const double s = fast_rcp(x * x);
+    double acc = R.get(LC_K0 + M - 1);
+#pragma unroll
+    for (int m = M - 2; m >= 0; --m) acc = __builtin_fma(acc, s, R.get(LC_K0 + m));
+    return acc * s;
+}
+
+// NOTE: LaneRec::get must only be used in wave-uniform control flow.  v_readlane reads lanes
+// regardless of EXEC, and inside a divergent branch the compiler is free to reuse the record's
+// VGPR in the lanes that are inactive there, so a cross-lane read would see clobbered data.
+// The cold path below therefore goes back to memory records through a scalarised pointer.
+
+// Cold path of the tile kernel: one 64-pixel chunk of one line that touches the line core (or a
+// line outside the fast domain).  Out of line on purpose: it keeps the hot loop's registers and
+// instruction footprint small.
+__device__ __attribute__((noinline)) double cold_line_tau(double wv, double g, const double* rec) {
+    // the pointer is wave-uniform but arrives in VGPRs: scalarise it so the record fields are
+    // fetched with scalar loads (valid under any EXEC mask)
+    const unsigned long long pv = reinterpret_cast<unsigned long long>(rec);
+    const unsigned int plo = __builtin_amdgcn_readfirstlane((unsigned int)pv);
+    const unsigned int phi = __builtin_amdgcn_readfirstlane((unsigned int)(pv >> 32));
+    const double* __restrict__ urec = reinterpret_cast<const double*>(((unsigned long long)phi << 32) | plo);
+    PixelX xp{wv, g};
+    return line_tau_wofz(xp, urec);
 }
 
 template <class XP>
@@ -214,6 +274,26 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __re
 // tile kernel
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_THREADS = 256;
+constexpr int RB = 4;             // 64-pixel chunks per wave pass (register blocking / ILP)
+
+// s * Horner_M(K, s) for RB independent chunks with the same M; K from the lane-held record.
+template <int M>
+__device__ __forceinline__ void wing_rb(const double (&x)[RB], const LaneRec& R, double (&tau)[RB]) {
+    double s[RB], acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) s[r] = fast_rcp(x[r] * x[r]);
+    const double kt = R.get(LC_K0 + M - 1);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = kt;
+#pragma unroll
+    for (int m = M - 2; m >= 0; --m) {
+        const double km = R.get(LC_K0 + m);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_fma(acc[r], s[r], km);
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) tau[r] = __builtin_fma(acc[r], s[r], tau[r]);
+}
 
 template <int METHOD, int OUT>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
 __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const double* __restrict__ lc,
@@ -229,41 +309,166 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
     const double* __restrict__ lcw = lc + (size_t)w * I.L * LC_STRIDE;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // LSF taps held across lanes (first 64 taps), fetched now so the load is long done at the LSF
+    const double ktaps = I.kflip[min(lane, I.K - 1)];
+    double* __restrict__ daw = fl + I.span + 4;        // Dawson table for the line cores (16-B aligned)
+    if (METHOD == 0) {
+        dawson_to_lds(daw, threadIdx.x, TILE_THREADS);
+        __syncthreads();
+    }
 
-    for (int i = threadIdx.x; i < n_eval; i += TILE_THREADS) {
-        const int q = min(max(q0 + i, 0), I.P - 1);      // edge replication = evaluate the clamped pixel
-        PixelX xp{I.wave[q], I.ginv[q]};
-        double tau = 0.0;
-        for (int l = 0; l < I.L; ++l) {
-            const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
-            tau += (METHOD == 0) ? line_tau_wofz(xp, rec) : line_tau_fast(xp, rec);
+    // ---- optical depth -> exp(-tau) into LDS.  Each wave owns 256 consecutive evaluated pixels
+    //      per pass (RB chunks of 64); lines are the outer loop so that a line's constants are
+    //      fetched once and feed RB independent evaluations.
+    for (int base = wid * (64 * RB); base < n_eval; base += TILE_THREADS * RB) {
+        double g[RB], wv[RB], tau[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = min(base + r * 64 + lane, n_eval - 1);
+            const int q = min(max(q0 + i, 0), I.P - 1);   // edge replication = evaluate the clamped pixel
+            g[r] = I.ginv[q];
+            wv[r] = I.wave[q];
+            tau[r] = 0.0;
         }
-        fl[i] = exp(-tau);                                // voigt_model.py:217
+#if defined(VP_ABLATE) && VP_ABLATE == 4
+        if (false) {
+#else
+        if (METHOD == 0) {
+#endif
+            for (int l0 = 0; l0 < I.L; l0 += 64) {
+                unsigned long long todo[RB];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) todo[r] = 0ull;
+                const int l1 = min(I.L, l0 + 64);
+                double rec_next = lcw[(size_t)l0 * LC_STRIDE + lane];
+                for (int l = l0; l < l1; ++l) {
+                    const LaneRec R{rec_next};
+                    rec_next = lcw[(size_t)min(l + 1, I.L - 1) * LC_STRIDE + lane];   // prefetch the next line
+                    const unsigned long long bit = 1ull << (l - l0);
+                    const double A = R.get(LC_A), B = R.get(LC_B);
+                    double x[RB];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) x[r] = __builtin_fma(A, g[r], -B);
+                    if (R.mode() != 0) {
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) todo[r] |= bit;
+                        continue;
+                    }
+                    const double xm = fmin(fmin(fabs(x[0]), fabs(x[1])), fmin(fabs(x[2]), fabs(x[3])));
+                    if (VP_NONE_BELOW(xm, 100.0)) {
+                        if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, R, tau);
+                        else if (VP_NONE_BELOW(xm, 500.0)) wing_rb<3>(x, R, tau);
+                        else wing_rb<4>(x, R, tau);
+                        continue;
+                    }
+                    double xf[RB];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) xf[r] = faithful_x(wv[r], g[r], R);
+                    if (VP_NONE_BELOW(xm, 30.0)) { wing_rb<6>(xf, R, tau); continue; }
+                    if (VP_NONE_BELOW(xm, 14.0)) { wing_rb<9>(xf, R, tau); continue; }
+                    if (VP_NONE_BELOW(xm, X_CORE)) { wing_rb<NWING>(xf, R, tau); continue; }
+                    // some chunk of this wave touches the line core (|x| < 8): evaluate the core series
+                    // for every lane of such a chunk (no divergence); lanes of a mixed chunk that lie
+                    // outside the core radius take the 14-term wing value.  All branches are
+                    // wave-uniform, so the lane-held record stays readable.
+                    const double T = R.get(LC_T), ya = R.get(LC_Y), ea2 = R.get(LC_EA2);
+                    const int nodd = R.nodd();
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const double xa = fabs(x[r]);
+                        if (VP_NONE_BELOW(xa, X_CORE)) {
+                            tau[r] += wing_tau<NWING>(xf[r], R);
+                        } else {
+                            double h = T * core_taylor_H_lds(xf[r], ya, ea2, nodd, daw);
+                            if (__ballot(xa >= X_CORE) != 0ull) {
+                                const double rw = wing_tau<NWING>(xf[r], R);
+                                h = (xa >= X_CORE) ? rw : h;
+                            }
+                            tau[r] += h;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    unsigned long long m = todo[r];
+#if defined(VP_ABLATE) && VP_ABLATE == 1
+                    m = 0;
+#endif
+                    while (m) {
+                        const int l = l0 + __builtin_ctzll(m);
+                        m &= m - 1;
+                        tau[r] += cold_line_tau(wv[r], g[r], lcw + (size_t)l * LC_STRIDE);
+                    }
+                }
+            }
+        } else {
+            for (int l = 0; l < I.L; ++l) {
+                const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) tau[r] += line_tau_fast(PixelX{wv[r], g[r]}, rec);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = base + r * 64 + lane;
+#if defined(VP_ABLATE) && VP_ABLATE == 3
+            if (i < n_eval) fl[i] = 1.0 - tau[r];
+#else
+            if (i < n_eval) fl[i] = exp(-tau[r]);                 // voigt_model.py:217
+#endif
+        }
     }
     __syncthreads();
 
+    // ---- LSF from LDS (taps broadcast from lanes), chi^2 term, reduce -----------------------------
     double acc = 0.0;
-    for (int i = threadIdx.x; i < nout; i += TILE_THREADS) {
-        const int p = p0 + i;
-        double m;
-        if (OUT == 2) {
-            m = fl[i + I.halo_lo];
-        } else {
-            m = 0.0;
-            for (int j = 0; j < I.K; ++j) m = __builtin_fma(I.kflip[j], fl[i + j], m);
+    for (int ib = 0; ib < nout; ib += TILE_THREADS * RB) {
+        double m[RB];
+        int idx[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            idx[r] = ib + r * TILE_THREADS + threadIdx.x;
+            m[r] = 0.0;
         }
-        if (OUT == 0) {
-            const double r = I.flux[p] - m;
-            acc = __builtin_fma(r * r, I.w[p], acc);      // (flux-model)^2 * inv_sigma2
+        if (OUT == 2) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) m[r] = fl[min(idx[r], nout - 1) + I.halo_lo];
         } else {
-            out[(size_t)w * out_stride + p] = m;
+            const LaneRec KT{ktaps};
+#if defined(VP_ABLATE) && VP_ABLATE == 2
+            const int kfirst = 1;
+#else
+            const int kfirst = min(I.K, 64);
+#endif
+            for (int j = 0; j < kfirst; ++j) {
+                const double kj = KT.get(j);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fl[min(idx[r], nout - 1) + j], m[r]);
+            }
+            for (int j = 64; j < I.K; ++j) {       // long tabulated kernels: remaining taps from memory
+                const double kj = I.kflip[j];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fl[min(idx[r], nout - 1) + j], m[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (idx[r] < nout) {
+                const int p = p0 + idx[r];
+                if (OUT == 0) {
+                    const double d = I.flux[p] - m[r];
+                    acc = __builtin_fma(d * d, I.w[p], acc);      // (flux-model)^2 * inv_sigma2
+                } else {
+                    out[(size_t)w * out_stride + p] = m[r];
+                }
+            }
         }
     }
     if (OUT == 0) {
         acc = wave_sum(acc);
         double* red = fl + I.span;
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        if (lane == 0) red[wid] = acc;
         __syncthreads();
         if (threadIdx.x == 0) out[(size_t)w * out_stride + out_offset + t] = (red[0] + red[1]) + (red[2] + red[3]);
     }

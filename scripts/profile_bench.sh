@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes for bench.py.
+# Usage: scripts/profile_bench.sh <tag> [bench args...]
+set -e
+TAG=${1:-r1}; shift || true
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--no-cpu-baseline --steps 200 --warmup 20 $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $ARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py $ARGS > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.err || true
+find $OUT -name "*.csv" | head -50
+python3 scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1 || true
+cat $OUT/summary.txt
