@@ -154,7 +154,7 @@ int ensure_workspace(vp_ctx* c, int W) {
 template <int OUT>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
                  int W, hipStream_t s) {
-    dim3 grid(in.dev.ntiles, W);
+    dim3 grid(W, in.dev.ntiles);
     if (in.dev.method == VP_VOIGT_FAST)
         hipLaunchKernelGGL((vp::tile_kernel<1, OUT>), grid, dim3(vp::TILE_THREADS), in.lds_bytes, s, in.dev, lc, flags,
                            out, stride, offset);
@@ -339,7 +339,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
-    in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES) * sizeof(double);
+    in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES + Kuse) * sizeof(double);
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
     c->inst.push_back(std::move(in));
     c->meta_dirty = true;

@@ -73,6 +73,41 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return r;
 }
 
+// 1/d to ~2e-15 relative (v_rcp_f64 delivers ~24 bits; one Newton step squares the error).  Enough
+// for the wing series, whose terms only need ~1e-14.
+__device__ __forceinline__ double fast_rcp1(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(e, r, r);
+}
+
+// exp(-t) for t >= 0 (flux = exp(-tau), Gaussian core exp(-x^2)) without the library's special-case
+// selects: n = rint(-t log2 e), two-step Cody-Waite reduction, degree-13 Taylor polynomial on
+// |r| <= ln2/2 (truncation 4e-18), scaling by v_ldexp (which underflows to 0 gracefully).  t is
+// clamped at 800 (exp(-800) = 0 in double); NaN handling is done at the walker level (prep kernel),
+// so a NaN here may come out as 0.
+__device__ __forceinline__ double exp_neg(double t) {
+    const double x = -fmin(t, 800.0);
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01, x);       // ln2 high part
+    r = __builtin_fma(n, -1.90821492927058770002e-10, r);              // ln2 low part
+    double p = 1.60590438368216145994e-10;                             // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878680989792e-09);
+    p = __builtin_fma(p, r, 2.50521083854417187751e-08);
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
 // x as the reference rounds it (voigt_model.py:204,144,150) without divisions:
 //   wr   = RN(wave / d)        via  q0 = wave*rd, exact residual, one correction
 //   freq = RN(c_freq / wr)     via  f0 = (c_freq*d)*g  (g = RN(1/wave)), exact residual, correction
@@ -94,7 +129,7 @@ __device__ __forceinline__ double faithful_x(double wave, double g, const double
 // Wing optical depth of one line: s * Horner_M(K, s), K premultiplied by N f constant a/sqrt(pi).
 template <int M>
 __device__ __forceinline__ double wing_tau(double x, const double* __restrict__ K) {
-    const double s = fast_rcp(x * x);
+    const double s = fast_rcp1(x * x);
     double acc = K[M - 1];
 #pragma unroll
     for (int m = M - 2; m >= 0; --m) acc = __builtin_fma(acc, s, K[m]);
@@ -157,7 +192,7 @@ __device__ __forceinline__ double core_taylor_H(double x, double a, double ea2, 
     }
     const double c = 1.1283791670955125739;          // 2/sqrt(pi)
     double vp = c * F, vc = c * G;                    // v_0, v_1
-    const double E = exp(-ax * ax);
+    const double E = exp_neg(ax * ax);
     const double a2 = a * a;
     double apow = -a;                                 // (-1)^k a^(2k-1) with alternating sign folded in
     double acc = apow * vc;
@@ -202,7 +237,7 @@ __device__ __forceinline__ double core_taylor_H_lds(double x, double a, double e
     }
     const double c = 1.1283791670955125739;          // 2/sqrt(pi)
     double vp = c * F, vc = c * G;                    // v_0, v_1
-    const double E = exp(-ax * ax);
+    const double E = exp_neg(ax * ax);
     const double a2 = a * a;
     double apow = -a;
     double acc = apow * vc;

@@ -185,13 +185,13 @@ __device__ __forceinline__ double line_tau_wofz(const XP& xp, const double* __re
     const double xa = fabs(xc);
     const double* __restrict__ K = rec + LC_K0;
     if (mode == 0) {
-        if (VP_NONE_BELOW(xa, 100.0)) {            // far wings: the 1-FMA x is accurate enough
+        if (VP_NONE_BELOW(xa, 30.0)) {             // far wings: the 1-FMA x is accurate enough
             if (VP_NONE_BELOW(xa, 3000.0)) return wing_tau<2>(xc, K);
             if (VP_NONE_BELOW(xa, 500.0)) return wing_tau<3>(xc, K);
-            return wing_tau<4>(xc, K);
+            if (VP_NONE_BELOW(xa, 100.0)) return wing_tau<4>(xc, K);
+            return wing_tau<6>(xc, K);
         }
         const double xf = xp.faithful(rec);        // reproduce the reference's rounding of x
-        if (VP_NONE_BELOW(xa, 30.0)) return wing_tau<6>(xf, K);
         if (VP_NONE_BELOW(xa, 14.0)) return wing_tau<9>(xf, K);
         if (VP_NONE_BELOW(xa, X_CORE)) return wing_tau<NWING>(xf, K);
         // line core: evaluated for every lane of the chunk (no divergence); lanes beyond the core
@@ -238,7 +238,7 @@ __device__ __forceinline__ double faithful_x(double wave, double g, const LaneRe
 
 template <int M>
 __device__ __forceinline__ double wing_tau(double x, const LaneRec& R) {
-    const double s = fast_rcp(x * x);
+    const double s = fast_rcp1(x * x);
     double acc = R.get(LC_K0 + M - 1);
 #pragma unroll
     for (int m = M - 2; m >= 0; --m) acc = __builtin_fma(acc, s, R.get(LC_K0 + m));
@@ -281,7 +281,7 @@ template <int M>
 __device__ __forceinline__ void wing_rb(const double (&x)[RB], const LaneRec& R, double (&tau)[RB]) {
     double s[RB], acc[RB];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) s[r] = fast_rcp(x[r] * x[r]);
+    for (int r = 0; r < RB; ++r) s[r] = fast_rcp1(x[r] * x[r]);
     const double kt = R.get(LC_K0 + M - 1);
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = kt;
@@ -301,7 +301,9 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
                                                             double* __restrict__ out, int out_stride,
                                                             int out_offset) {
     extern __shared__ double fl[];      // span doubles (+ 4 for the block reduce)
-    const int t = blockIdx.x, w = blockIdx.y;
+    // walkers are the fast grid dimension and the (short) last tile comes last, so the tail of the
+    // launch is filled with the cheapest workgroups
+    const int t = blockIdx.y, w = blockIdx.x;
     if (OUT == 0 && flags[w]) return;   // out-of-bounds walker: likelihood is not evaluated
     const int p0 = t * I.TP;
     const int p1 = min(p0 + I.TP, I.P);
@@ -310,13 +312,11 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
     const int q0 = p0 - I.halo_lo;
     const double* __restrict__ lcw = lc + (size_t)w * I.L * LC_STRIDE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // LSF taps held across lanes (first 64 taps), fetched now so the load is long done at the LSF
-    const double ktaps = I.kflip[min(lane, I.K - 1)];
     double* __restrict__ daw = fl + I.span + 4;        // Dawson table for the line cores (16-B aligned)
-    if (METHOD == 0) {
-        dawson_to_lds(daw, threadIdx.x, TILE_THREADS);
-        __syncthreads();
-    }
+    double* __restrict__ ktap = daw + DAW_LDS_DOUBLES; // LSF taps, read back as LDS broadcasts
+    for (int j = threadIdx.x; j < I.K; j += TILE_THREADS) ktap[j] = I.kflip[j];
+    if (METHOD == 0) dawson_to_lds(daw, threadIdx.x, TILE_THREADS);
+    __syncthreads();
 
     // ---- optical depth -> exp(-tau) into LDS.  Each wave owns 256 consecutive evaluated pixels
     //      per pass (RB chunks of 64); lines are the outer loop so that a line's constants are
@@ -356,16 +356,19 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
                         continue;
                     }
                     const double xm = fmin(fmin(fabs(x[0]), fabs(x[1])), fmin(fabs(x[2]), fabs(x[3])));
-                    if (VP_NONE_BELOW(xm, 100.0)) {
-                        if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, R, tau);
-                        else if (VP_NONE_BELOW(xm, 500.0)) wing_rb<3>(x, R, tau);
-                        else wing_rb<4>(x, R, tau);
+                    if (VP_NONE_BELOW(xm, 30.0)) {        // the 1-FMA x is accurate enough out here
+                        if (VP_NONE_BELOW(xm, 100.0)) {
+                            if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, R, tau);
+                            else if (VP_NONE_BELOW(xm, 500.0)) wing_rb<3>(x, R, tau);
+                            else wing_rb<4>(x, R, tau);
+                        } else {
+                            wing_rb<6>(x, R, tau);
+                        }
                         continue;
                     }
                     double xf[RB];
 #pragma unroll
                     for (int r = 0; r < RB; ++r) xf[r] = faithful_x(wv[r], g[r], R);
-                    if (VP_NONE_BELOW(xm, 30.0)) { wing_rb<6>(xf, R, tau); continue; }
                     if (VP_NONE_BELOW(xm, 14.0)) { wing_rb<9>(xf, R, tau); continue; }
                     if (VP_NONE_BELOW(xm, X_CORE)) { wing_rb<NWING>(xf, R, tau); continue; }
                     // some chunk of this wave touches the line core (|x| < 8): evaluate the core series
@@ -377,7 +380,11 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
 #pragma unroll
                     for (int r = 0; r < RB; ++r) {
                         const double xa = fabs(x[r]);
+#if defined(VP_ABLATE) && VP_ABLATE == 1
+                        if (true) {
+#else
                         if (VP_NONE_BELOW(xa, X_CORE)) {
+#endif
                             tau[r] += wing_tau<NWING>(xf[r], R);
                         } else {
                             double h = T * core_taylor_H_lds(xf[r], ya, ea2, nodd, daw);
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
 #if defined(VP_ABLATE) && VP_ABLATE == 3
             if (i < n_eval) fl[i] = 1.0 - tau[r];
 #else
-            if (i < n_eval) fl[i] = exp(-tau[r]);                 // voigt_model.py:217
+            if (i < n_eval) fl[i] = exp_neg(tau[r]);              // voigt_model.py:217
 #endif
         }
     }
@@ -435,21 +442,18 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
 #pragma unroll
             for (int r = 0; r < RB; ++r) m[r] = fl[min(idx[r], nout - 1) + I.halo_lo];
         } else {
-            const LaneRec KT{ktaps};
 #if defined(VP_ABLATE) && VP_ABLATE == 2
-            const int kfirst = 1;
+            const int kn = 1;
 #else
-            const int kfirst = min(I.K, 64);
+            const int kn = I.K;
 #endif
-            for (int j = 0; j < kfirst; ++j) {
-                const double kj = KT.get(j);
+            const double* fb[RB];
 #pragma unroll
-                for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fl[min(idx[r], nout - 1) + j], m[r]);
-            }
-            for (int j = 64; j < I.K; ++j) {       // long tabulated kernels: remaining taps from memory
-                const double kj = I.kflip[j];
+            for (int r = 0; r < RB; ++r) fb[r] = fl + min(idx[r], nout - 1);
+            for (int j = 0; j < kn; ++j) {
+                const double kj = ktap[j];                        // uniform address: LDS broadcast
 #pragma unroll
-                for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fl[min(idx[r], nout - 1) + j], m[r]);
+                for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fb[r][j], m[r]);
             }
         }
 #pragma unroll
