@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -46,6 +47,7 @@ struct vp_ctx {
     double* d_lc = nullptr;      // (capW, capL, LC_STRIDE)
     double* d_partial = nullptr; // (capW, total_tiles)
     int* d_flags = nullptr;      // (capW)
+    unsigned int* d_ticket = nullptr;  // (capW) arrival counters of the fused final reduction
     int* d_tile_off = nullptr;   // (n_inst + 1)
     double* d_sum_logw = nullptr;
     bool meta_dirty = true;
@@ -138,29 +140,31 @@ int ensure_workspace(vp_ctx* c, int W) {
     // a stream-ordered previous call may still be using the old buffers
     HIP_TRY(c, hipDeviceSynchronize());
     const int newW = std::max(W, c->capW);
-    for (void* p : {(void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial, (void*)c->d_flags})
+    for (void* p : {(void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial, (void*)c->d_flags, (void*)c->d_ticket})
         if (p) HIP_TRY(c, hipFree(p));
-    c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->capW = 0;
+    c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->d_ticket = nullptr; c->capW = 0;
     HIP_TRY(c, hipMalloc((void**)&c->d_theta, (size_t)newW * std::max(c->D, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_out, (size_t)newW * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_lc, (size_t)newW * maxL * vp::LC_STRIDE * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_partial, (size_t)newW * std::max(c->total_tiles, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_flags, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMemset(c->d_flags, 0, (size_t)newW * sizeof(int)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_ticket, (size_t)newW * sizeof(unsigned int)));
+    HIP_TRY(c, hipMemset(c->d_ticket, 0, (size_t)newW * sizeof(unsigned int)));
     c->capW = newW; c->capL = maxL; c->cap_tiles = c->total_tiles;
     return VP_OK;
 }
 
 template <int OUT>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
-                 int W, hipStream_t s) {
+                 int W, hipStream_t s, const vp::FinalizeArgs& fin) {
     dim3 grid(W, in.dev.ntiles);
     if (in.dev.method == VP_VOIGT_FAST)
-        hipLaunchKernelGGL((vp::tile_kernel<1, OUT>), grid, dim3(vp::TILE_THREADS), in.lds_bytes, s, in.dev, lc, flags,
-                           out, stride, offset);
+        hipLaunchKernelGGL((vp::tile_kernel<1, OUT>), grid, dim3(in.dev.span / 4 > 256 ? 256 : in.dev.span / 4), in.lds_bytes, s, in.dev, lc, flags,
+                           out, stride, offset, fin);
     else
-        hipLaunchKernelGGL((vp::tile_kernel<0, OUT>), grid, dim3(vp::TILE_THREADS), in.lds_bytes, s, in.dev, lc, flags,
-                           out, stride, offset);
+        hipLaunchKernelGGL((vp::tile_kernel<0, OUT>), grid, dim3(in.dev.span / 4 > 256 ? 256 : in.dev.span / 4), in.lds_bytes, s, in.dev, lc, flags,
+                           out, stride, offset, fin);
 }
 
 size_t prof_mark(vp_ctx* c, hipStream_t s) {
@@ -174,17 +178,20 @@ size_t prof_mark(vp_ctx* c, hipStream_t s) {
     return i;
 }
 
-// enqueue the whole lnprob pipeline for device-resident theta / out
+// enqueue the whole lnprob pipeline for device-resident theta / out: per instrument a prep launch
+// (line records; the first one also applies the box prior and writes -inf rows) and a tile launch;
+// the last-arriving tile workgroup of each walker performs the final reduction.
 int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
     int tile_off = 0;
     const bool prof = c->profiling;
     size_t m0 = prof ? prof_mark(c, s) : 0;
+    const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off, c->d_sum_logw, d_out, (int)c->inst.size(), c->total_tiles};
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines,
-                           c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0);
+                           c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0, d_out);
         size_t m1 = prof ? prof_mark(c, s) : 0;
-        launch_tile<0>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s);
+        launch_tile<0>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin);
         if (prof) {
             size_t m2 = prof_mark(c, s);
             c->spans.push_back({m0, m1, 0});
@@ -193,9 +200,6 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         }
         tile_off += in.dev.ntiles;
     }
-    hipLaunchKernelGGL(vp::finalize_kernel, dim3((W + 255) / 256), dim3(256), 0, s, c->d_partial, c->total_tiles,
-                       c->d_tile_off, c->d_sum_logw, (int)c->inst.size(), c->d_flags, d_out, W);
-    if (prof) { size_t m3 = prof_mark(c, s); c->spans.push_back({m0, m3, 2}); }
     HIP_TRY(c, hipGetLastError());
     return VP_OK;
 }
@@ -250,7 +254,7 @@ int vp_ctx_destroy(vp_ctx* c) {
     hipDeviceSynchronize();
     for (auto& in : c->inst) for (void* p : in.allocs) hipFree(p);
     for (void* p : {(void*)c->d_lb, (void*)c->d_ub, (void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial,
-                    (void*)c->d_flags, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch})
+                    (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch})
         if (p) hipFree(p);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -296,6 +300,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     if (lsf_mode != VP_LSF_NONE && (K <= 0 || !taps)) return fail(c, VP_EINVAL, "vp_add_instrument: lsf_mode set but no taps");
     if (lsf_mode != VP_LSF_NONE && (K % 2) == 0) return fail(c, VP_EINVAL, "vp_add_instrument: the number of taps must be odd");
     if (K > 2049) return fail(c, VP_EINVAL, "vp_add_instrument: more than 2049 LSF taps is not supported");
+    if (L > 4096) return fail(c, VP_EINVAL, "vp_add_instrument: more than 4096 lines per instrument is not supported");
     for (int l = 0; l < L; ++l) {
         if (N_idx[l] < 0 || N_idx[l] >= c->D || b_idx[l] < 0 || b_idx[l] >= c->D || v_idx[l] < 0 || v_idx[l] >= c->D)
             return fail(c, VP_EINVAL, "vp_add_instrument: theta index of line " + std::to_string(l) + " outside [0, D)");
@@ -332,15 +337,21 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     in.lines = vp::LinesDev{L, d_l0, d_g, d_f, d_z, d_n, d_b, d_v};
     vp::InstDev& d = in.dev;
     d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method;
-    int span = 1024;
+    // Tile geometry: one wave evaluates 256 consecutive pixels (4 chunks of 64, register-blocked);
+    // a workgroup is 1, 2 or 4 such waves.  Single-wave workgroups need no cross-wave barrier and
+    // let the hardware balance the walkers' tiles; longer LSFs take wider tiles to keep the halo
+    // (K-1 re-evaluated pixels per tile) a small fraction.
+    int span = Kuse <= 33 ? 256 : Kuse <= 65 ? 512 : 1024;
+    if (const char* sp = getenv("RBVFIT_AMD_SPAN")) span = atoi(sp);     // tuning experiments
     if (Kuse > 257) span = std::min(8192, ((4 * Kuse + 63) / 64) * 64);
     const int need = P + Kuse - 1;
-    if (need < span) span = ((need + 63) / 64) * 64;
+    if (need < span) span = std::max(256, ((need + 255) / 256) * 256);
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
-    in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES + Kuse) * sizeof(double);
+    in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES + Kuse + (span / 64) * ((L + 63) / 64)) * sizeof(double);
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
+    if (const char* pad = getenv("RBVFIT_AMD_LDS_PAD")) in.lds_bytes += (size_t)atol(pad);   // occupancy experiments
     c->inst.push_back(std::move(in));
     c->meta_dirty = true;
     if (inst_index) *inst_index = (int)c->inst.size() - 1;
@@ -404,9 +415,10 @@ int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* 
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const Instrument& in = c->inst[inst];
     hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines, c->d_lb,
-                       c->d_ub, c->d_lc, c->d_flags, 0);
-    if (convolved) launch_tile<1>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s);
-    else launch_tile<2>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s);
+                       c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr);
+    const vp::FinalizeArgs nofin{};
+    if (convolved) launch_tile<1>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin);
+    else launch_tile<2>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin);
     HIP_TRY(c, hipGetLastError());
     return VP_OK;
 }

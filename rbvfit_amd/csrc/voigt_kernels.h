@@ -33,6 +33,15 @@ struct LinesDev {          // static per-instrument line tables (CompiledModelDa
     const int* v_idx;
 };
 
+struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of a walker)
+    unsigned int* ticket;        // (W) arrival counters, zero between launches
+    const int* tile_off;         // (n_inst + 1) offsets into a walker's partial row
+    const double* sum_logw;      // (n_inst) sum of log inv_sigma2
+    double* lnprob;              // (W) output
+    int n_inst;
+    int total_tiles;             // arrivals per walker over all instruments
+};
+
 struct InstDev {
     int P;         // pixels
     int L;         // lines
@@ -84,15 +93,18 @@ __device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, 
     if (!(a >= 0.0) || !(a < 7.0)) mode = 2;         // a < 0, a >= 7, NaN
     else if (a > 0.1) mode = 1;
     const double a2 = a * a;
-    // Gaussian-sum table and its plain sum
-    double tb = 0.0;
-    if (lane < NCORE) {
-        const double hn = ALG916_H * (double)(lane + 1);
-        const double hn2 = hn * hn;
-        tb = exp(-hn2) / (hn2 + a2);
+    // Gaussian-sum table and its plain sum: only lines outside the fast domain need them
+    double S1 = 0.0;
+    if (mode == 1) {                                  // wave-uniform
+        double tb = 0.0;
+        if (lane < NCORE) {
+            const double hn = ALG916_H * (double)(lane + 1);
+            const double hn2 = hn * hn;
+            tb = exp(-hn2) / (hn2 + a2);
+        }
+        S1 = wave_sum(tb);
+        if (lane < NCORE) rec[LC_TBL0 + lane] = (0.5 * ALG916_C * a) * tb;
     }
-    const double S1 = wave_sum(tb);
-    if (lane < NCORE) rec[LC_TBL0 + lane] = (0.5 * ALG916_C * a) * tb;
     // wing coefficients
     if (lane < NWING) {
         double cm = 0.0;
@@ -102,8 +114,7 @@ __device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, 
     if (lane == 0) {
         rec[LC_T] = T;
         rec[LC_Y] = a;
-        double ec = (mode == 2) ? 0.0 : erfcx(a);
-        rec[LC_ACOS] = ec - (ALG916_C * a) * S1;
+        rec[LC_ACOS] = (mode == 1) ? erfcx(a) - (ALG916_C * a) * S1 : 0.0;
         reinterpret_cast<int*>(rec + LC_MODE)[0] = mode;
         reinterpret_cast<int*>(rec + LC_MODE)[1] = core_terms(a);
         rec[LC_EA2] = exp(a2);
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
                                                         LinesDev T, const double* __restrict__ lb,
                                                         const double* __restrict__ ub,
                                                         double* __restrict__ lc, int* __restrict__ flags,
-                                                        int do_flags) {
+                                                        int do_flags, double* __restrict__ lnprob_out) {
     const int w = blockIdx.x / T.L, l = blockIdx.x % T.L;
     const int lane = threadIdx.x;
     const double* th = theta + (size_t)w * D;
@@ -125,7 +136,10 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         int oob = 0;
         for (int d = lane; d < D; d += 64) oob |= (th[d] < lb[d]) || (th[d] > ub[d]);   // vfit_mcmc.py:293
         const int any = __any(oob);
-        if (lane == 0) flags[w] = any ? 1 : 0;
+        if (lane == 0) {
+            flags[w] = any ? 1 : 0;
+            if (any && lnprob_out) lnprob_out[w] = -__builtin_inf();   // vfit_mcmc.py:350-351
+        }
     }
     double* rec = lc + ((size_t)w * T.L + l) * LC_STRIDE;
     const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
@@ -273,7 +287,7 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __re
 // ---------------------------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------------------------
-constexpr int TILE_THREADS = 256;
+constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span = 256 pixels per wave)
 constexpr int RB = 4;             // 64-pixel chunks per wave pass (register blocking / ILP)
 
 // s * Horner_M(K, s) for RB independent chunks with the same M; K from the lane-held record.
@@ -296,15 +310,16 @@ __device__ __forceinline__ void wing_rb(const double (&x)[RB], const LaneRec& R,
 }
 
 template <int METHOD, int OUT>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
-__global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const double* __restrict__ lc,
+__global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const double* __restrict__ lc,
                                                             const int* __restrict__ flags,
                                                             double* __restrict__ out, int out_stride,
-                                                            int out_offset) {
-    extern __shared__ double fl[];      // span doubles (+ 4 for the block reduce)
+                                                            int out_offset, FinalizeArgs F) {
+    // LDS: fl[span] tau -> flux | red[4] | Dawson table | LSF taps | per-chunk "line core" masks
+    extern __shared__ double fl[];
     // walkers are the fast grid dimension and the (short) last tile comes last, so the tail of the
     // launch is filled with the cheapest workgroups
     const int t = blockIdx.y, w = blockIdx.x;
-    if (OUT == 0 && flags[w]) return;   // out-of-bounds walker: likelihood is not evaluated
+    const int oob = (OUT == 0) ? flags[w] : 0;   // tested below, after the first loads are in flight
     const int p0 = t * I.TP;
     const int p1 = min(p0 + I.TP, I.P);
     const int nout = p1 - p0;
@@ -312,15 +327,20 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
     const int q0 = p0 - I.halo_lo;
     const double* __restrict__ lcw = lc + (size_t)w * I.L * LC_STRIDE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int TILE_THREADS = blockDim.x, nwaves = blockDim.x >> 6;
     double* __restrict__ daw = fl + I.span + 4;        // Dawson table for the line cores (16-B aligned)
     double* __restrict__ ktap = daw + DAW_LDS_DOUBLES; // LSF taps, read back as LDS broadcasts
+    unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(ktap + I.K);
+    const int nwords = (I.L + 63) >> 6;                // 64 lines per mask word
+    const int nchunks = (n_eval + 63) >> 6;
     for (int j = threadIdx.x; j < I.K; j += TILE_THREADS) ktap[j] = I.kflip[j];
-    if (METHOD == 0) dawson_to_lds(daw, threadIdx.x, TILE_THREADS);
-    __syncthreads();
+    if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
 
-    // ---- optical depth -> exp(-tau) into LDS.  Each wave owns 256 consecutive evaluated pixels
-    //      per pass (RB chunks of 64); lines are the outer loop so that a line's constants are
-    //      fetched once and feed RB independent evaluations.
+    // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
+    //      Each wave owns 256 consecutive evaluated pixels per pass (RB chunks of 64); lines are the
+    //      outer loop so that a line's constants are fetched once and feed RB independent
+    //      evaluations.  Chunks that touch a line core (or a line outside the fast domain) are only
+    //      flagged; their tau goes to LDS raw and phase B finishes them.
     for (int base = wid * (64 * RB); base < n_eval; base += TILE_THREADS * RB) {
         double g[RB], wv[RB], tau[RB];
 #pragma unroll
@@ -331,11 +351,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
             wv[r] = I.wave[q];
             tau[r] = 0.0;
         }
-#if defined(VP_ABLATE) && VP_ABLATE == 4
-        if (false) {
-#else
+        bool pending[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) pending[r] = false;
         if (METHOD == 0) {
-#endif
             for (int l0 = 0; l0 < I.L; l0 += 64) {
                 unsigned long long todo[RB];
 #pragma unroll
@@ -371,42 +390,23 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
                     for (int r = 0; r < RB; ++r) xf[r] = faithful_x(wv[r], g[r], R);
                     if (VP_NONE_BELOW(xm, 14.0)) { wing_rb<9>(xf, R, tau); continue; }
                     if (VP_NONE_BELOW(xm, X_CORE)) { wing_rb<NWING>(xf, R, tau); continue; }
-                    // some chunk of this wave touches the line core (|x| < 8): evaluate the core series
-                    // for every lane of such a chunk (no divergence); lanes of a mixed chunk that lie
-                    // outside the core radius take the 14-term wing value.  All branches are
-                    // wave-uniform, so the lane-held record stays readable.
-                    const double T = R.get(LC_T), ya = R.get(LC_Y), ea2 = R.get(LC_EA2);
-                    const int nodd = R.nodd();
+                    // some chunk of this wave touches the line core: flag it for phase B; the other
+                    // chunks get their 14-term wing value here (wave-uniform branches)
 #pragma unroll
                     for (int r = 0; r < RB; ++r) {
-                        const double xa = fabs(x[r]);
 #if defined(VP_ABLATE) && VP_ABLATE == 1
-                        if (true) {
+                        if (true) tau[r] += wing_tau<NWING>(xf[r], R);
 #else
-                        if (VP_NONE_BELOW(xa, X_CORE)) {
+                        if (VP_NONE_BELOW(fabs(x[r]), X_CORE)) tau[r] += wing_tau<NWING>(xf[r], R);
+                        else todo[r] |= bit;
 #endif
-                            tau[r] += wing_tau<NWING>(xf[r], R);
-                        } else {
-                            double h = T * core_taylor_H_lds(xf[r], ya, ea2, nodd, daw);
-                            if (__ballot(xa >= X_CORE) != 0ull) {
-                                const double rw = wing_tau<NWING>(xf[r], R);
-                                h = (xa >= X_CORE) ? rw : h;
-                            }
-                            tau[r] += h;
-                        }
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < RB; ++r) {
-                    unsigned long long m = todo[r];
-#if defined(VP_ABLATE) && VP_ABLATE == 1
-                    m = 0;
-#endif
-                    while (m) {
-                        const int l = l0 + __builtin_ctzll(m);
-                        m &= m - 1;
-                        tau[r] += cold_line_tau(wv[r], g[r], lcw + (size_t)l * LC_STRIDE);
-                    }
+                    pending[r] = pending[r] || (todo[r] != 0ull);
+                    const int c = (base >> 6) + r;
+                    if (lane == 0 && c < nchunks) cmask[c * nwords + (l0 >> 6)] = todo[r];
                 }
             }
         } else {
@@ -420,13 +420,76 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
         for (int r = 0; r < RB; ++r) {
             const int i = base + r * 64 + lane;
 #if defined(VP_ABLATE) && VP_ABLATE == 3
-            if (i < n_eval) fl[i] = 1.0 - tau[r];
+            if (i < n_eval) fl[i] = pending[r] ? tau[r] : 1.0 - tau[r];
 #else
-            if (i < n_eval) fl[i] = exp_neg(tau[r]);              // voigt_model.py:217
+            if (i < n_eval) fl[i] = pending[r] ? tau[r] : exp_neg(tau[r]);   // voigt_model.py:217
 #endif
         }
     }
     __syncthreads();
+
+    // ---- phase B: line cores.  The flagged chunks of the tile are dealt round-robin to the four
+    //      waves (balanced whatever their position), each chunk finished by one wave: core series
+    //      for every lane (no divergence), 14-term wing value for lanes of a mixed chunk beyond the
+    //      core radius, then exp.  Single instance of the core code keeps the hot loop's registers
+    //      low.  All control flow here is wave-uniform, so lane-held records stay readable.
+    if (METHOD == 0) {
+        // stage the Dawson table only if some chunk of this tile needs the core series (uniform)
+        unsigned int anycore = 0u;
+        for (int k = lane; k < nchunks * nwords; k += 64) {
+            const unsigned long long mw = cmask[k];
+            anycore |= (unsigned int)mw | (unsigned int)(mw >> 32);
+        }
+        if (__ballot(anycore != 0u) != 0ull) {
+            dawson_to_lds(daw, threadIdx.x, TILE_THREADS);
+            __syncthreads();
+        }
+        int kth = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            unsigned int any = 0u;
+            for (int wd = 0; wd < nwords; ++wd) {
+                const unsigned long long mw = cmask[c * nwords + wd];
+                any |= (unsigned int)mw | (unsigned int)(mw >> 32);
+            }
+            if (__builtin_amdgcn_readfirstlane(any) == 0u) continue;
+            if ((kth++ & (nwaves - 1)) != wid) continue;
+            const int i = c * 64 + lane;
+            const int ic = min(i, n_eval - 1);
+            const int q = min(max(q0 + ic, 0), I.P - 1);
+            const double gq = I.ginv[q], wq = I.wave[q];
+            double tau = fl[ic];
+            for (int wd = 0; wd < nwords; ++wd) {
+                unsigned long long m = cmask[c * nwords + wd];
+                {   // scalarise (mind the sign: readfirstlane returns int)
+                    const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)m);
+                    const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
+                    m = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
+                }
+                double rec_next = m ? lcw[(size_t)((wd << 6) + __builtin_ctzll(m)) * LC_STRIDE + lane] : 0.0;
+                while (m) {
+                    const int l = (wd << 6) + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
+                    const LaneRec R{rec_next};
+                    if (m) rec_next = lcw[(size_t)((wd << 6) + __builtin_ctzll(m)) * LC_STRIDE + lane];   // prefetch
+                    if (R.mode() != 0) {
+                        tau += cold_line_tau(wq, gq, rec);
+                        continue;
+                    }
+                    const double xf = faithful_x(wq, gq, R);
+                    const double xa = fabs(xf);
+                    double h = R.get(LC_T) * core_taylor_H_lds(xf, R.get(LC_Y), R.get(LC_EA2), R.nodd(), daw);
+                    if (__ballot(xa >= X_CORE) != 0ull) {
+                        const double rw = wing_tau<NWING>(xf, R);
+                        h = (xa >= X_CORE) ? rw : h;
+                    }
+                    tau += h;
+                }
+            }
+            if (i < n_eval) fl[i] = exp_neg(tau);
+        }
+        __syncthreads();
+    }
 
     // ---- LSF from LDS (taps broadcast from lanes), chi^2 term, reduce -----------------------------
     double acc = 0.0;
@@ -474,7 +537,33 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_kernel(InstDev I, const dou
         double* red = fl + I.span;
         if (lane == 0) red[wid] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) out[(size_t)w * out_stride + out_offset + t] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) {
+            double tile_sum = red[0];
+            for (int k = 1; k < nwaves; ++k) tile_sum += red[k];
+            // Publish this tile's partial and take a ticket; the workgroup that draws the last ticket
+            // of the walker (over all instruments) sums the partials in fixed order.  Hand-off by
+            // 8-byte agent-scope atomics on both sides (write-through store, drained before the
+            // ticket; L1-bypassing loads after it) -- placement-independent, no fences needed.
+            double* row = out + (size_t)w * out_stride;
+            __hip_atomic_store(row + out_offset + t, tile_sum, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+#if defined(VP_ABLATE) && VP_ABLATE == 4
+            return;
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int ticket = __hip_atomic_fetch_add(F.ticket + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == (unsigned int)(F.total_tiles - 1)) {
+                double total = 0.0;
+                for (int k = 0; k < F.n_inst; ++k) {
+                    double sk = 0.0;
+                    for (int tt = F.tile_off[k]; tt < F.tile_off[k + 1]; ++tt)
+                        sk += __hip_atomic_load(row + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    total += -0.5 * (sk - F.sum_logw[k]);           // vfit_mcmc.py:309-311
+                }
+                F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
+                __hip_atomic_store(F.ticket + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 

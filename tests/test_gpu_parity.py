@@ -72,3 +72,22 @@ def test_unconvolved_flux_matches_oracle(oracle):
     for i in range(3):
         ref = oracle.model_flux(data, z["thetas"][i], z["G__wave"], return_unconvolved=True)
         np.testing.assert_allclose(got[i], ref, rtol=0, atol=FLUX_ATOL)
+
+
+def test_repeated_calls_with_changing_theta_are_fresh():
+    """The fused final reduction hands partial sums between workgroups (possibly on different
+    XCDs) through agent-scope atomics; a stale read would surface as a value of the previous call."""
+    z = load_golden("c3_mini")                 # two instruments -> tickets span two launches
+    rng = np.random.default_rng(7)
+    with engine_from_fixture(z) as eng:
+        base = z["thetas"][:12]
+        ref_first = eng.lnprob(base)
+        for it in range(25):
+            th = np.clip(z["theta_true"] + 0.05 * rng.standard_normal((64, z["theta_true"].size)) *
+                         np.concatenate([np.full(8, 1.0), np.full(8, 5.0), np.full(8, 10.0)]),
+                         z["lb"] + 1e-9, z["ub"] - 1e-9)
+            got = eng.lnprob(th)
+            k = rng.integers(0, 64, 4)
+            singles = np.array([eng.lnprob(th[i])[0] for i in k])
+            assert np.array_equal(got[k], singles)
+        assert np.array_equal(eng.lnprob(base), ref_first)
