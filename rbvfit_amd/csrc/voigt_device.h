@@ -47,7 +47,7 @@ enum {
     LC_T = 7,      // (N*f)*constant
     LC_Y = 8,      // a = gamma/(4 pi b_f)
     LC_ACOS = 9,   // erfcx(a) - c*a*sum_n tbl_n
-    LC_MODE = 10,  // int[0]: 0: a<=0.1 ; 1: 0.1<a<7 ; 2: a>=7 or a<0 or non-finite (generic path)
+    LC_MODE = 10,  // int[0]: 0: a<=0.1 ; 1: 0.1<a<7 ; 2: a>=7 or a<0 (generic path) ; 3: non-finite -> NaN
                    // int[1]: number of odd Taylor-in-a terms of the core series (mode 0)
     LC_K0 = 11,    // 21 wing coefficients  K_m = T*(a/sqrt(pi))*C_m(a^2)
     LC_TBL0 = 32,  // 26 entries  0.5*c*a*exp(-h^2 n^2)/(h^2 n^2 + a^2), n = 1..26
@@ -307,7 +307,8 @@ __device__ inline double generic_H(double x, const double* __restrict__ rec, int
         if (ax < X_CORE) return core_H(x, rec);
         return cf_rew(ax, y);
     }
-    // mode 2: a >= 7 (continued fraction everywhere), a < 0 (reflection), or non-finite
+    if (mode == 3) return __builtin_nan("");       // non-finite line constants
+    // mode 2: a >= 7 (continued fraction everywhere) or a < 0 (reflection)
     if (y >= 7.0) return cf_rew(ax, y);
     if (y < 0.0) {
         // w(z) for Im z < 0:  w(z) = 2 exp(-z^2) - w(-z)  =>  Re = 2 e^{y^2-x^2} cos(2xy) - H(|y|,x)

@@ -90,8 +90,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // wave; lane-parallel over table entries.
 __device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, double T, double a) {
     int mode = 0;
-    if (!(a >= 0.0) || !(a < 7.0)) mode = 2;         // a < 0, a >= 7, NaN
+    if (!(a >= 0.0) || !(a < 7.0)) mode = 2;         // a < 0, a >= 7
     else if (a > 0.1) mode = 1;
+    if (!(fabs(a) <= 1.79e308) || !(fabs(T) <= 1.79e308)) mode = 3;   // NaN/inf constants: the line poisons tau
+                                                                       // with NaN, as the reference's arithmetic does
     const double a2 = a * a;
     // Gaussian-sum table and its plain sum: only lines outside the fast domain need them
     double S1 = 0.0;
@@ -153,7 +155,9 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
     const double constant = ATOMIC_CONSTANT / (freq0 * b);   // :146
     const double a = gam / (12.566370614359172 * b_f); // :149  (4*np.pi)
     const double Tl = (N * fo) * constant;             // :158 (left-to-right)
-    fill_record(rec, lane, Tl, a);
+    const double cfd0 = C_FREQ * d;
+    const bool xok = (fabs(cfd0 / b_f) <= 1.79e308) && (fabs(freq0 / b_f) <= 1.79e308);
+    fill_record(rec, lane, xok ? Tl : __builtin_nan(""), a);
     if (lane == 0) {
         const double cfd = C_FREQ * d;
         rec[LC_A] = cfd / b_f;
@@ -288,7 +292,10 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __re
 // tile kernel
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span = 256 pixels per wave)
-constexpr int RB = 4;             // 64-pixel chunks per wave pass (register blocking / ILP)
+#ifndef VP_RB
+#define VP_RB 4
+#endif
+constexpr int RB = VP_RB;         // 64-pixel chunks per wave pass (register blocking / ILP)
 
 // s * Horner_M(K, s) for RB independent chunks with the same M; K from the lane-held record.
 template <int M>
@@ -374,7 +381,9 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                         for (int r = 0; r < RB; ++r) todo[r] |= bit;
                         continue;
                     }
-                    const double xm = fmin(fmin(fabs(x[0]), fabs(x[1])), fmin(fabs(x[2]), fabs(x[3])));
+                    double xm = fabs(x[0]);
+#pragma unroll
+                    for (int r = 1; r < RB; ++r) xm = fmin(xm, fabs(x[r]));
                     if (VP_NONE_BELOW(xm, 30.0)) {        // the 1-FMA x is accurate enough out here
                         if (VP_NONE_BELOW(xm, 100.0)) {
                             if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, R, tau);
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                     tau += h;
                 }
             }
-            if (i < n_eval) fl[i] = exp_neg(tau);
+            if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg(tau);   // NaN survives (poisoned lines)
         }
         __syncthreads();
     }

@@ -148,3 +148,33 @@ class vfit:
 
     def close(self):
         self.engine.close()
+
+    # -- walker loop (host) ----------------------------------------------------------------------
+    def runmcmc(self, optimize: bool = False, verbose: bool = False, use_pool: bool = False, seed=None):
+        """Mirror of ``vfit.runmcmc`` (vfit_mcmc.py:492-561) reduced to the sampling itself: walker
+        initialisation (:442-466) and ``no_of_steps`` ensemble steps with ONE batched GPU lnprob
+        call per half-ensemble.  emcee is used with ``vectorize=True`` when it is installed,
+        otherwise ``rbvfit_amd.sampler.StretchMoveSampler``.  ``use_pool`` must stay False: a HIP
+        context cannot be shared with forked workers, and batching replaces the Pool."""
+        if use_pool:
+            raise ValueError("use_pool=True is not supported: the batched GPU lnprob replaces the fork Pool")
+        if optimize:
+            raise NotImplementedError("L-BFGS-B pre-optimisation is outside the accelerated path (SURVEY 8f N2)")
+        from .sampler import StretchMoveSampler, initialize_walkers
+        rng = np.random.default_rng(seed)
+        guesses = initialize_walkers(self.theta, self.lb, self.ub, self.no_of_Chain, self.perturbation,
+                                     self.lnprob, rng)
+        try:
+            import emcee  # noqa: F401
+            sampler = emcee.EnsembleSampler(self.no_of_Chain, self.ndim, self.lnprob, vectorize=True)
+            sampler.run_mcmc(guesses, self.no_of_steps, progress=verbose)
+        except ImportError:
+            sampler = StretchMoveSampler(self.no_of_Chain, self.ndim, self.lnprob, seed=seed)
+            sampler.run_mcmc(guesses, self.no_of_steps)
+        self.sampler = sampler
+        self.mcmc_flag = True
+        burn = int(0.2 * self.no_of_steps)
+        self.samples = sampler.get_chain(discard=burn, flat=True)
+        lo, med, hi = np.percentile(self.samples, [16, 50, 84], axis=0)     # compute_best_theta (:563-570)
+        self.best_theta, self.low_theta, self.high_theta = med, lo, hi
+        return sampler

@@ -1,0 +1,209 @@
+"""GPU tests at BASELINE.json's full sizes (C1..C4) and of the host mirror on the device.
+
+At full size the oracle is only run on a handful of rows (it needs 1-200 ms per row); the rest of
+the batch is covered by size-independent properties: lnprob recomputed on the host from the
+engine's own model flux, additivity over instruments, permutation invariance, -inf/NaN classes.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, FLUX_ATOL, LNPROB_RTOL, LNPROB_ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_instruments(wl):
+    from oracle import voigt_oracle as vo
+    insts = []
+    for data, (wave, flux, err) in zip(wl.tables, wl.spectra):
+        od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors,
+                                data.N_indices, data.b_indices, data.v_indices,
+                                data.taps if data.taps is not None else np.zeros(0), data.lsf_mode, data.voigt_method)
+        insts.append(vo.OracleInstrument.from_error(od, wave, flux, err))
+    return vo, insts
+
+
+def _host_lnlike_from_flux(wl, thetas):
+    """-0.5 sum[(flux-model)^2 w - log w] with the model rows taken from the engine."""
+    total = np.zeros(len(thetas))
+    for k, (wave, flux, err) in enumerate(wl.spectra):
+        model = wl.engine.model_flux(k, thetas)
+        w = 1.0 / err ** 2
+        total += -0.5 * np.sum((flux - model) ** 2 * w - np.log(w), axis=1)
+    return total
+
+
+@pytest.mark.parametrize("name,walkers,n_oracle,n_prop", [("C1", 512, 24, 64), ("C2", 1024, 4, 16),
+                                                         ("C3", 256, 3, 16), ("C4", 32, 2, 4)])
+def test_full_size_config(name, walkers, n_oracle, n_prop):
+    from rbvfit_amd.workloads import make_workload
+    wl = make_workload(name, walkers=walkers)
+    try:
+        th = wl.thetas.copy()
+        th[5, 0] = wl.lb[0] - 0.25                    # out of bounds -> -inf, model not evaluated
+        th[7, -1] = wl.ub[-1] + 3.0
+        got = wl.engine.lnprob(th)
+        assert got.shape == (walkers,)
+        assert np.isneginf(got[5]) and np.isneginf(got[7])
+        ok = np.ones(walkers, bool); ok[[5, 7]] = False
+        assert np.all(np.isfinite(got[ok]))
+        # oracle on the first rows
+        vo, insts = _oracle_instruments(wl)
+        ref = vo.lnprob_batch(th[:n_oracle], wl.lb, wl.ub, insts)
+        np.testing.assert_allclose(got[:n_oracle], ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        # property: lnprob == likelihood recomputed on the host from the engine's model flux
+        rows = np.arange(8, 8 + n_prop)
+        np.testing.assert_allclose(got[rows], _host_lnlike_from_flux(wl, th[rows]), rtol=1e-11, atol=1e-7)
+        # property: permutation of the walkers permutes the result, bit for bit
+        perm = np.random.default_rng(3).permutation(walkers)
+        assert np.array_equal(wl.engine.lnprob(th[perm]), got[perm])
+        # flux rows vs oracle
+        for k, inst in enumerate(insts):
+            fl = wl.engine.model_flux(k, th[:2])
+            for i in range(2):
+                np.testing.assert_allclose(fl[i], vo.model_flux(inst.data, th[i], inst.wave), rtol=0, atol=FLUX_ATOL)
+    finally:
+        wl.engine.close()
+
+
+def test_joint_fit_is_the_sum_of_its_instruments():
+    """C3: lnprob of the 2-instrument context == sum of single-instrument contexts (shared theta)."""
+    import rbvfit_amd
+    from rbvfit_amd.workloads import make_workload
+    wl = make_workload("C3", walkers=64)
+    try:
+        joint = wl.engine.lnprob(wl.thetas)
+        parts = np.zeros(64)
+        for data, (wave, flux, err) in zip(wl.tables, wl.spectra):
+            with rbvfit_amd.Engine(0) as e:
+                e.set_bounds(wl.lb, wl.ub)
+                e.add_instrument(wave, flux, 1 / err ** 2, np.log(1 / err ** 2), **data.engine_kwargs())
+                parts += e.lnprob(wl.thetas)
+        np.testing.assert_allclose(joint, parts, rtol=1e-13, atol=0)
+    finally:
+        wl.engine.close()
+
+
+def test_nan_and_zero_error_classes_follow_the_reference():
+    """NaN theta is in-bounds for the reference's comparisons and propagates; error == 0 gives
+    inf - inf = NaN in the reference's likelihood."""
+    from oracle import voigt_oracle as vo
+    import rbvfit_amd
+    z = load_golden("ragged_1000")
+    insts = vo.instruments_from_fixture(z)
+    th = z["thetas"][:4].copy()
+    th[1, 2] = np.nan
+    g = lambda k: z[f"G__{k}"]
+    err = g("error").copy(); err[10] = 0.0
+    with np.errstate(all="ignore"):
+        w, lw = 1.0 / err ** 2, np.log(1.0 / err ** 2)
+        bad = vo.OracleInstrument(insts[0].data, insts[0].wave, insts[0].flux, w, lw)
+        ref_nan = vo.lnprob_batch(th, z["lb"], z["ub"], insts)
+        ref_zero = vo.lnprob_batch(th, z["lb"], z["ub"], [bad])
+    with rbvfit_amd.Engine(0) as e:
+        e.set_bounds(z["lb"], z["ub"])
+        kw = dict(lambda0=g("lambda0"), gamma=g("gamma"), f=g("f"), zfac=g("zfac"), N_idx=g("N_idx"), b_idx=g("b_idx"),
+                  v_idx=g("v_idx"), taps=g("taps"), lsf_mode=int(g("lsf_mode")))
+        e.add_instrument(g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), **kw)
+        got_nan = e.lnprob(th)
+    with rbvfit_amd.Engine(0) as e:
+        e.set_bounds(z["lb"], z["ub"])
+        e.add_instrument(g("wave"), g("flux"), w, lw, **kw)
+        got_zero = e.lnprob(th)
+    assert np.array_equal(np.isnan(got_nan), np.isnan(ref_nan)) and np.isnan(got_nan[1])
+    assert np.array_equal(np.isnan(got_zero), np.isnan(ref_zero)) and np.all(np.isnan(got_zero))
+
+
+@pytest.mark.parametrize("b_value", [0.05, 0.002, 1e-4])
+def test_lines_outside_the_fast_domain(b_value):
+    """Damping parameter a > 0.1 (tiny b): continued fraction / Gaussian-sum generic path vs the
+    oracle's scipy wofz.  b = 0.05 -> a ~ 0.15; 0.002 -> a ~ 3.6; 1e-4 -> a ~ 73."""
+    from oracle import voigt_oracle as vo
+    import rbvfit_amd
+    z = load_golden("c0_mgii")
+    data = vo.data_from_fixture(z, "G")
+    th = z["theta_true"].copy()
+    th[2] = b_value                      # first component's Doppler parameter
+    th[0] = 12.0
+    lb, ub = z["lb"].copy(), z["ub"].copy()
+    lb[2] = 0.0
+    insts = vo.instruments_from_fixture(z)
+    ref_flux = vo.model_flux(data, th, z["G__wave"])
+    ref_lnp = vo.lnprob(th, lb, ub, insts)
+    g = lambda k: z[f"G__{k}"]
+    with rbvfit_amd.Engine(0) as e:
+        e.set_bounds(lb, ub)
+        e.add_instrument(g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"), g("f"),
+                         g("zfac"), g("N_idx"), g("b_idx"), g("v_idx"), taps=g("taps"), lsf_mode=int(g("lsf_mode")))
+        fl = e.model_flux(0, th)[0]
+        lnp = e.lnprob(th)[0]
+    np.testing.assert_allclose(fl, ref_flux, rtol=0, atol=FLUX_ATOL)
+    np.testing.assert_allclose(lnp, ref_lnp, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+
+
+def test_vfit_mirror_and_compiled_model_on_device():
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    from rbvfit_amd.vfit import vfit
+    z = load_golden("real_cos")                       # float32 flux/error from the reference's saved fit
+    cfg = FitConfiguration()
+    cfg.add_system(0.0, "SiII", [1190.4158, 1193.2897], 1)
+    cfg.add_system(0.162005, "HI", [1025.7223], 1)
+    model = VoigtModel(cfg, FWHM=str(z["fwhm"]))
+    inst = {"COS": {"model": model, "wave": z["COS__wave"], "flux": z["COS__flux"], "error": z["COS__error"]}}
+    fit = vfit(inst, z["theta_true"], z["lb"], z["ub"], no_of_Chain=20, no_of_steps=30)
+    try:
+        assert fit.instrument_data["COS"]["inv_sigma2"].dtype == np.float32         # trap T4
+        one = fit.lnprob(z["thetas"][0])
+        assert isinstance(one, float) and abs(one - 205.56708945563835) < 1e-7
+        batch = fit.lnprob(z["thetas"])
+        np.testing.assert_allclose(batch, z["lnprob"], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        oob = z["thetas"][0].copy(); oob[0] = z["lb"][0] - 1
+        assert fit.lnprob(oob) == -np.inf and fit.lnprior(oob) == -np.inf and np.isfinite(fit.lnlike(oob))
+        insts = vo.instruments_from_fixture(z)
+        assert abs(fit.lnlike(oob) - vo.lnlike(oob, insts)) < 1e-7
+        # compiled model: single theta -> (P,), batch -> (W, P); evaluate() ignores voigt_method (T10)
+        cm = model.compile()
+        f1 = cm.model_flux(z["thetas"][0], z["COS__wave"])
+        assert f1.shape == (184,)
+        np.testing.assert_allclose(f1, z["COS__model_flux"][0], rtol=0, atol=FLUX_ATOL)
+        fb = cm(z["thetas"][:4], z["COS__wave"])
+        np.testing.assert_allclose(fb, z["COS__model_flux"], rtol=0, atol=FLUX_ATOL)
+        un = model.evaluate(z["thetas"][0], z["COS__wave"], return_unconvolved=True)
+        ref_un = vo.model_flux(insts[0].data, z["thetas"][0], z["COS__wave"], return_unconvolved=True)
+        np.testing.assert_allclose(un, ref_un, rtol=0, atol=FLUX_ATOL)
+        with pytest.raises(TypeError):
+            import pickle
+            pickle.dumps(cm)
+        with pytest.raises(ValueError):
+            fit.runmcmc(use_pool=True)
+        s = fit.runmcmc(seed=5)                        # 20 walkers x 30 steps, batched lnprob
+        assert fit.samples.shape[1] == 6 and np.all(np.isfinite(s.lnprobability))
+        assert fit.best_theta.shape == (6,)
+    finally:
+        fit.close()
+
+
+def test_engine_argument_errors():
+    import rbvfit_amd
+    z = load_golden("one_px")
+    g = lambda k: z[f"G__{k}"]
+    with rbvfit_amd.Engine(0) as e:
+        with pytest.raises(rbvfit_amd.RbvfitAmdError):        # bounds first
+            e.add_instrument(g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"),
+                             g("f"), g("zfac"), g("N_idx"), g("b_idx"), g("v_idx"))
+        e.set_bounds(z["lb"], z["ub"])
+        with pytest.raises(rbvfit_amd.RbvfitAmdError):        # lnprob before any instrument
+            e.lnprob(z["thetas"])
+        with pytest.raises(rbvfit_amd.RbvfitAmdError):        # theta index outside [0, D)
+            e.add_instrument(g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"),
+                             g("f"), g("zfac"), g("N_idx") + 100, g("b_idx"), g("v_idx"))
+        with pytest.raises(rbvfit_amd.RbvfitAmdError):        # even number of taps
+            e.add_instrument(g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"),
+                             g("f"), g("zfac"), g("N_idx"), g("b_idx"), g("v_idx"), taps=[0.5, 0.5], lsf_mode=1)
+        e.add_instrument(g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"),
+                         g("f"), g("zfac"), g("N_idx"), g("b_idx"), g("v_idx"), taps=g("taps"), lsf_mode=int(g("lsf_mode")))
+        with pytest.raises(ValueError):
+            e.lnprob(np.zeros((3, 5)))
+        assert e.lnprob(np.zeros((0, 6))).shape == (0,)      # empty batch
+        np.testing.assert_allclose(e.lnprob(z["thetas"])[:4], z["lnprob"][:4], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)

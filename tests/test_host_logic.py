@@ -1,0 +1,162 @@
+"""Host-side mirror of the reference interface (CPU only): table construction, bounds, taps,
+validation, walker sharding, sampler."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from rbvfit_amd import atomic, LSF_SCIPY_NEAREST, LSF_ASTROPY_EXTEND, LSF_NONE
+from rbvfit_amd.lsf import gaussian_taps
+from rbvfit_amd.model import FitConfiguration, VoigtModel, tables_from_rbvfit
+from rbvfit_amd.vfit import set_bounds, vfit
+from rbvfit_amd.dist import shard_bounds
+from rbvfit_amd.sampler import StretchMoveSampler, initialize_walkers
+
+MGII = [(0.348, "MgII", [2796.35, 2803.53], 2)]
+MULTI = [(0.348, "MgII", [2796.35, 2803.53], 3), (0.348, "FeII", [2600.17, 2586.65, 2382.77], 3),
+         (0.348, "CIV", [1548.20, 1550.77], 2)]
+STRESS = [(0.348 + 0.01 * i, "MgII", [2796.35, 2803.53], 8) for i in range(4)]
+
+
+def _model(spec, fwhm="6.5", **kw):
+    cfg = FitConfiguration()
+    for z, ion, tr, nc in spec:
+        cfg.add_system(z, ion, tr, nc)
+    return VoigtModel(cfg, FWHM=fwhm, **kw)
+
+
+@pytest.mark.parametrize("spec,fixture", [(MGII, "c0_mgii"), (MULTI, "c2_mini"), (STRESS, "c4_mini")])
+def test_tables_equal_the_reference_compiled_model(spec, fixture):
+    """Line order, theta index maps, float32 atomic data and z factors of the reference's
+    CompiledModelData (voigt_model.py:386-442) captured in the golden fixtures."""
+    z = load_golden(fixture)
+    m = _model(spec)
+    np.testing.assert_array_equal(m.atomic_lambda0, z["G__lambda0"])
+    assert m.atomic_gamma.dtype == np.float32 and m.atomic_f.dtype == np.float32        # trap T1
+    np.testing.assert_array_equal(m.atomic_gamma.astype(np.float64), z["G__gamma"])
+    np.testing.assert_array_equal(m.atomic_f.astype(np.float64), z["G__f"])
+    np.testing.assert_array_equal(m.z_factors, z["G__zfac"])
+    np.testing.assert_array_equal(m.N_indices, z["G__N_idx"])
+    np.testing.assert_array_equal(m.b_indices, z["G__b_idx"])
+    np.testing.assert_array_equal(m.v_indices, z["G__v_idx"])
+    np.testing.assert_allclose(m.taps, z["G__taps"], rtol=5e-16)
+    assert m.lsf_mode == LSF_SCIPY_NEAREST == int(z["G__lsf_mode"])
+
+
+def test_real_cos_tables():
+    z = load_golden("real_cos")
+    cfg = FitConfiguration()
+    cfg.add_system(0.0, "SiII", [1190.4158, 1193.2897], 1)
+    cfg.add_system(0.162005, "HI", [1025.7223], 1)
+    m = VoigtModel(cfg, FWHM=str(z["fwhm"]))
+    np.testing.assert_array_equal(m.atomic_lambda0, z["COS__lambda0"])
+    np.testing.assert_array_equal(m.N_indices, [0, 0, 1])
+    np.testing.assert_array_equal(m.b_indices, [2, 2, 3])
+    np.testing.assert_array_equal(m.v_indices, [4, 4, 5])
+    assert m.taps.size == 9
+
+
+def test_kernel_branches():
+    assert _model(MGII, None).lsf_mode == LSF_NONE and _model(MGII, None).taps is None
+    m = _model(MGII, "6.5", kernel_taps=[0.1, 0.5, 0.2])
+    assert m.lsf_mode == LSF_ASTROPY_EXTEND
+    assert abs(gaussian_taps(6.5, normalize=True).sum() - 1.0) < 1e-15
+    assert abs(gaussian_taps(6.5).sum() - 0.999972) < 1e-6          # trap T2: raw taps are not normalised
+    with pytest.raises(ValueError):
+        _model(MGII, "6.5", voigt_method="nope")
+
+
+def test_atomic_lookup_mirrors_rb_setline():
+    info = atomic.lookup(2796.3, "closest")
+    assert info["wave"] == 2796.352 and info["fval"].dtype == np.float32 and info["gamma"].dtype == np.float32
+    assert info["fval"] == np.float32(0.6123) and info["name"] == "MgII 2796"
+    with pytest.raises(KeyError):
+        atomic.lookup(2796.3, "Exact")
+    with pytest.raises(ValueError):
+        atomic.lookup(2796.3, "nearest")
+
+
+def test_set_bounds_matches_fixture():
+    z = load_golden("c2_mini")
+    th = z["theta_true"]
+    C = th.size // 3
+    _, lb, ub = set_bounds(th[:C], th[C:2 * C], th[2 * C:])
+    np.testing.assert_array_equal(lb, z["lb"])
+    np.testing.assert_array_equal(ub, z["ub"])
+    _, lb2, _ = set_bounds([13.0], [20.0], [0.0], Nlow=[10.0])
+    assert lb2[0] == 10.0
+
+
+def test_vfit_validation_errors_match_the_reference():
+    with pytest.raises(TypeError):
+        vfit._validate_unified_instrument_data([1, 2])
+    with pytest.raises(ValueError):
+        vfit._validate_unified_instrument_data({})
+    with pytest.raises(ValueError):
+        vfit._validate_unified_instrument_data({"A": {"model": None, "wave": [1], "flux": [1]}})
+    with pytest.raises(ValueError):
+        vfit._validate_unified_instrument_data({"A": {"model": None, "wave": [1, 2], "flux": [1], "error": [1, 2]}})
+    with pytest.raises(ValueError):
+        vfit._validate_guesses([1.0, 5.0], [0.0, 0.0], [2.0, 2.0])
+    with pytest.raises(ValueError):
+        vfit._validate_guesses([1.0], [0.0, 0.0], [2.0, 2.0])
+
+
+def test_tables_from_rbvfit_duck_typing():
+    class Gaussian1DKernel:           # stands for astropy's class of the same name
+        array = np.array([0.25, 0.5, 0.25])
+
+    class Data:
+        atomic_lambda0 = np.array([2796.352]); atomic_gamma = np.array([2.612e8], dtype=np.float32)
+        atomic_f = np.array([0.6123], dtype=np.float32); z_factors = np.array([1.348])
+        N_indices = np.array([0]); b_indices = np.array([1]); v_indices = np.array([2])
+        kernel = Gaussian1DKernel(); n_lines = 1; total_components = 1; voigt_method = "fast"
+
+    class Compiled:
+        data = Data()
+
+    t = tables_from_rbvfit(Compiled())
+    assert t.lsf_mode == LSF_SCIPY_NEAREST and t.voigt_method == "fast" and t.taps.size == 3
+    kw = t.engine_kwargs()
+    assert kw["gamma"].dtype == np.float64 and kw["gamma"][0] == float(np.float32(2.612e8))
+
+
+def test_shard_bounds_cover_all_rows_once():
+    for W in (0, 1, 3, 7, 50, 512, 2048):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = shard_bounds(W, world, r)
+                assert 0 <= lo <= hi <= W
+                seen += list(range(lo, hi))
+            assert seen == list(range(W))
+
+
+def test_stretch_move_sampler_recovers_a_gaussian():
+    mu, sig = np.array([1.0, -2.0, 0.5]), np.array([0.5, 2.0, 1.0])
+    calls = []
+
+    def lp(th):
+        calls.append(th.shape)
+        return -0.5 * np.sum(((th - mu) / sig) ** 2, axis=1)
+
+    s = StretchMoveSampler(40, 3, lp, seed=3)
+    p0 = initialize_walkers(mu, mu - 10, mu + 10, 40, 1e-2, lp, np.random.default_rng(0))
+    s.run_mcmc(p0, 1500)
+    c = s.get_chain(discard=500, flat=True)
+    assert np.all(np.abs(c.mean(0) - mu) < 0.15 * sig) and np.all(np.abs(c.std(0) / sig - 1) < 0.1)
+    assert all(sh == (20, 3) for sh in calls[2:])           # one batched call per half-ensemble
+    assert 0.3 < s.acceptance_fraction.mean() < 0.9
+    with pytest.raises(ValueError):
+        StretchMoveSampler(5, 3, lp)
+    with pytest.raises(ValueError):
+        StretchMoveSampler(40, 3, lambda th: np.full(len(th), np.nan)).run_mcmc(p0, 1)
+
+
+def test_initialize_walkers_redraws_non_finite_rows():
+    lb, ub = np.array([0.0, 0.0]), np.array([1.0, 1.0])
+    lp = lambda th: np.where(th[:, 0] > 0.5, 0.0, -np.inf)
+    pos = initialize_walkers([0.5, 0.5], lb, ub, 64, 0.1, lp, np.random.default_rng(1))
+    assert np.all(pos[:, 0] > 0.5) and np.all((pos > lb) & (pos < ub))
+    with pytest.raises(RuntimeError):
+        initialize_walkers([0.5, 0.5], lb, ub, 8, 0.1, lambda th: np.full(len(th), -np.inf),
+                           np.random.default_rng(1), max_attempts=3)
