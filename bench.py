@@ -50,7 +50,7 @@ def cpu_baseline(wl, budget_s=12.0):
     try:
         from oracle import c_oracle
         co = c_oracle.COracle(insts, wl.lb, wl.ub)
-        cores = os.cpu_count() or 1
+        cores = min(16, len(os.sched_getaffinity(0)))     # the GPU box's CPU share per GPU
         co.lnprob_batch(wl.thetas[:cores], nthreads=cores)
         t0 = time.perf_counter()
         reps = 0
