@@ -25,6 +25,10 @@ struct Instrument {
     double* d_flux = nullptr;
     double* d_w = nullptr;
     size_t lds_bytes = 0;
+    // host copies for the "can any in-bounds walker leave the fast domain?" analysis
+    std::vector<double> h_lambda0, h_gamma;
+    std::vector<int> h_bidx;
+    bool needs_generic = true;
 };
 
 }  // namespace
@@ -48,6 +52,8 @@ struct vp_ctx {
     double* d_partial = nullptr; // (capW, total_tiles)
     int* d_flags = nullptr;      // (capW)
     unsigned int* d_ticket = nullptr;  // (capW) arrival counters of the fused final reduction
+    int* d_genflag = nullptr;    // (capW) walkers with lines outside the fast domain (per instrument pass)
+    std::vector<double> h_lb;    // host copy of the lower bounds
     int* d_tile_off = nullptr;   // (n_inst + 1)
     double* d_sum_logw = nullptr;
     bool meta_dirty = true;
@@ -140,9 +146,9 @@ int ensure_workspace(vp_ctx* c, int W) {
     // a stream-ordered previous call may still be using the old buffers
     HIP_TRY(c, hipDeviceSynchronize());
     const int newW = std::max(W, c->capW);
-    for (void* p : {(void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial, (void*)c->d_flags, (void*)c->d_ticket})
+    for (void* p : {(void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial, (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag})
         if (p) HIP_TRY(c, hipFree(p));
-    c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->d_ticket = nullptr; c->capW = 0;
+    c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->d_ticket = nullptr; c->d_genflag = nullptr; c->capW = 0;
     HIP_TRY(c, hipMalloc((void**)&c->d_theta, (size_t)newW * std::max(c->D, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_out, (size_t)newW * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_lc, (size_t)newW * maxL * vp::LC_STRIDE * sizeof(double)));
@@ -151,20 +157,38 @@ int ensure_workspace(vp_ctx* c, int W) {
     HIP_TRY(c, hipMemset(c->d_flags, 0, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMalloc((void**)&c->d_ticket, (size_t)newW * sizeof(unsigned int)));
     HIP_TRY(c, hipMemset(c->d_ticket, 0, (size_t)newW * sizeof(unsigned int)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_genflag, (size_t)newW * sizeof(int)));
+    HIP_TRY(c, hipMemset(c->d_genflag, 0, (size_t)newW * sizeof(int)));
     c->capW = newW; c->capL = maxL; c->cap_tiles = c->total_tiles;
     return VP_OK;
 }
 
-template <int OUT>
+template <int OUT, bool GENERIC>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
-                 int W, hipStream_t s, const vp::FinalizeArgs& fin) {
+                 int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag) {
     dim3 grid(W, in.dev.ntiles);
-    if (in.dev.method == VP_VOIGT_FAST)
-        hipLaunchKernelGGL((vp::tile_kernel<1, OUT>), grid, dim3(in.dev.span / 4 > 256 ? 256 : in.dev.span / 4), in.lds_bytes, s, in.dev, lc, flags,
-                           out, stride, offset, fin);
-    else
-        hipLaunchKernelGGL((vp::tile_kernel<0, OUT>), grid, dim3(in.dev.span / 4 > 256 ? 256 : in.dev.span / 4), in.lds_bytes, s, in.dev, lc, flags,
-                           out, stride, offset, fin);
+    dim3 block(in.dev.span / 4 > 256 ? 256 : in.dev.span / 4);
+    if (in.dev.method == VP_VOIGT_FAST) {
+        if (!GENERIC)
+            hipLaunchKernelGGL((vp::tile_kernel<1, OUT, false>), grid, block, in.lds_bytes, s, in.dev, lc, flags, out,
+                               stride, offset, fin, genflag);
+    } else {
+        hipLaunchKernelGGL((vp::tile_kernel<0, OUT, GENERIC>), grid, block, in.lds_bytes, s, in.dev, lc, flags, out,
+                           stride, offset, fin, genflag);
+    }
+}
+
+// Can a walker inside the prior box have a line outside the fast domain (a > 0.1 or b <= 0)?
+// a = gamma lambda0 / (4 pi 1e13 b) is largest at the lower bound of b.  A 10 % margin covers the
+// difference between this estimate and the device arithmetic.
+void analyse_generic(vp_ctx* c, Instrument& in) {
+    in.needs_generic = false;
+    for (size_t l = 0; l < in.h_lambda0.size(); ++l) {
+        const double blo = c->h_lb.empty() ? 0.0 : c->h_lb[in.h_bidx[l]];
+        if (!(blo > 0.0)) { in.needs_generic = true; return; }
+        const double amax = std::fabs(in.h_gamma[l]) * in.h_lambda0[l] / (12.566370614359172 * 1e13 * blo);
+        if (!(amax < 0.09) || in.h_gamma[l] < 0.0) { in.needs_generic = true; return; }
+    }
 }
 
 size_t prof_mark(vp_ctx* c, hipStream_t s) {
@@ -188,10 +212,15 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off, c->d_sum_logw, d_out, (int)c->inst.size(), c->total_tiles};
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
+        const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
+        if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
         hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines,
-                           c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0, d_out);
+                           c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr);
         size_t m1 = prof ? prof_mark(c, s) : 0;
-        launch_tile<0>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin);
+        launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin,
+                              gen ? c->d_genflag : (const int*)nullptr);
+        if (gen)
+            launch_tile<0, true>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin, c->d_genflag);
         if (prof) {
             size_t m2 = prof_mark(c, s);
             c->spans.push_back({m0, m1, 0});
@@ -254,7 +283,7 @@ int vp_ctx_destroy(vp_ctx* c) {
     hipDeviceSynchronize();
     for (auto& in : c->inst) for (void* p : in.allocs) hipFree(p);
     for (void* p : {(void*)c->d_lb, (void*)c->d_ub, (void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial,
-                    (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch})
+                    (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch})
         if (p) hipFree(p);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -282,6 +311,8 @@ int vp_set_bounds(vp_ctx* c, int D, const double* lb, const double* ub) {
         c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->capW = 0;
     }
     c->D = D;
+    c->h_lb.assign(lb, lb + D);
+    for (auto& in : c->inst) analyse_generic(c, in);
     return VP_OK;
 }
 
@@ -351,6 +382,8 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
     in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES + Kuse + (span / 64) * ((L + 63) / 64)) * sizeof(double);
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
+    in.h_lambda0.assign(lambda0, lambda0 + L); in.h_gamma.assign(gamma, gamma + L); in.h_bidx.assign(b_idx, b_idx + L);
+    analyse_generic(c, in);
     if (const char* pad = getenv("RBVFIT_AMD_LDS_PAD")) in.lds_bytes += (size_t)atol(pad);   // occupancy experiments
     c->inst.push_back(std::move(in));
     c->meta_dirty = true;
@@ -414,11 +447,19 @@ int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* 
     if ((rc = ensure_workspace(c, W))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const Instrument& in = c->inst[inst];
+    const bool gen = in.dev.method == VP_VOIGT_WOFZ;      // model_flux has no prior box: theta may be anything
+    if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
     hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines, c->d_lb,
-                       c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr);
+                       c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr, gen ? c->d_genflag : (int*)nullptr);
     const vp::FinalizeArgs nofin{};
-    if (convolved) launch_tile<1>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin);
-    else launch_tile<2>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin);
+    const int* gf = gen ? c->d_genflag : (const int*)nullptr;
+    if (convolved) {
+        launch_tile<1, false>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
+        if (gen) launch_tile<1, true>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
+    } else {
+        launch_tile<2, false>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
+        if (gen) launch_tile<2, true>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
+    }
     HIP_TRY(c, hipGetLastError());
     return VP_OK;
 }

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
                                                         LinesDev T, const double* __restrict__ lb,
                                                         const double* __restrict__ ub,
                                                         double* __restrict__ lc, int* __restrict__ flags,
-                                                        int do_flags, double* __restrict__ lnprob_out) {
+                                                        int do_flags, double* __restrict__ lnprob_out,
+                                                        int* __restrict__ genflag) {
     const int w = blockIdx.x / T.L, l = blockIdx.x % T.L;
     const int lane = threadIdx.x;
     const double* th = theta + (size_t)w * D;
@@ -158,6 +159,8 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
     const double cfd0 = C_FREQ * d;
     const bool xok = (fabs(cfd0 / b_f) <= 1.79e308) && (fabs(freq0 / b_f) <= 1.79e308);
     fill_record(rec, lane, xok ? Tl : __builtin_nan(""), a);
+    // lines outside the fast domain (a > 0.1, a < 0): their walker goes to the generic kernel
+    if (genflag && lane == 0 && (!(a >= 0.0) || a > 0.1) && (fabs(a) <= 1.79e308)) genflag[w] = 1;
     if (lane == 0) {
         const double cfd = C_FREQ * d;
         rec[LC_A] = cfd / b_f;
@@ -293,7 +296,7 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __re
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span = 256 pixels per wave)
 #ifndef VP_RB
-#define VP_RB 4
+#define VP_RB 2
 #endif
 constexpr int RB = VP_RB;         // 64-pixel chunks per wave pass (register blocking / ILP)
 
@@ -316,17 +319,22 @@ __device__ __forceinline__ void wing_rb(const double (&x)[RB], const LaneRec& R,
     for (int r = 0; r < RB; ++r) tau[r] = __builtin_fma(acc[r], s[r], tau[r]);
 }
 
-template <int METHOD, int OUT>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
+// GENERIC = false: the fast instance (no out-of-line generic Faddeeva, ~77 VGPRs); it skips walkers
+// flagged in `genflag`.  GENERIC = true: full instance, processes ONLY the flagged walkers.  Every
+// (walker, tile) is therefore handled by exactly one of the two launches.
+template <int METHOD, int OUT, bool GENERIC>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
 __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const double* __restrict__ lc,
                                                             const int* __restrict__ flags,
                                                             double* __restrict__ out, int out_stride,
-                                                            int out_offset, FinalizeArgs F) {
+                                                            int out_offset, FinalizeArgs F,
+                                                            const int* __restrict__ genflag) {
     // LDS: fl[span] tau -> flux | red[4] | Dawson table | LSF taps | per-chunk "line core" masks
     extern __shared__ double fl[];
     // walkers are the fast grid dimension and the (short) last tile comes last, so the tail of the
     // launch is filled with the cheapest workgroups
     const int t = blockIdx.y, w = blockIdx.x;
     const int oob = (OUT == 0) ? flags[w] : 0;   // tested below, after the first loads are in flight
+    const int gen = genflag ? genflag[w] : 0;
     const int p0 = t * I.TP;
     const int p1 = min(p0 + I.TP, I.P);
     const int nout = p1 - p0;
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     const int nchunks = (n_eval + 63) >> 6;
     for (int j = threadIdx.x; j < I.K; j += TILE_THREADS) ktap[j] = I.kflip[j];
     if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
+    if (GENERIC ? (gen == 0) : (gen != 0)) return;   // the other launch owns this walker
 
     // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
     //      Each wave owns 256 consecutive evaluated pixels per pass (RB chunks of 64); lines are the
@@ -482,7 +491,8 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                     const LaneRec R{rec_next};
                     if (m) rec_next = lcw[(size_t)((wd << 6) + __builtin_ctzll(m)) * LC_STRIDE + lane];   // prefetch
                     if (R.mode() != 0) {
-                        tau += cold_line_tau(wq, gq, rec);
+                        if (GENERIC) tau += cold_line_tau(wq, gq, rec);
+                        else tau = __builtin_nan("");          // poisoned line (non-finite constants)
                         continue;
                     }
                     const double xf = faithful_x(wq, gq, R);
