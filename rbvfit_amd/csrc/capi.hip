@@ -380,7 +380,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
-    in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES + Kuse + (span / 64) * ((L + 63) / 64)) * sizeof(double);
+    in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES + Kuse + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
     in.h_lambda0.assign(lambda0, lambda0 + L); in.h_gamma.assign(gamma, gamma + L); in.h_bidx.assign(b_idx, b_idx + L);
     analyse_generic(c, in);

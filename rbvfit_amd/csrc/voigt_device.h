@@ -37,21 +37,23 @@ constexpr int LC_STRIDE = 64;   // doubles per record (512 B, one record = 4 x 1
 constexpr int NWING = 14;       // longest wing series (valid for |x| >= 8)
 constexpr int NCORE = 26;       // terms of the Gaussian sum (covers |x| < 7.2)
 enum {
+    // --- eager block: one 64-B scalar load feeds every tier with M <= 6 ---
     LC_A = 0,      // c_freq*(1+z_tot)/b_f           cheap x = fma(A, 1/wave, -B)
     LC_B = 1,      // freq0/b_f
-    LC_D = 2,      // 1+z_tot  (as the reference rounds it)
-    LC_RD = 3,     // RN(1/(1+z_tot))
-    LC_CFD = 4,    // c_freq*(1+z_tot)
-    LC_FREQ0 = 5,  // c_freq/lambda0
-    LC_IBF = 6,    // 1/b_f
-    LC_T = 7,      // (N*f)*constant
-    LC_Y = 8,      // a = gamma/(4 pi b_f)
-    LC_ACOS = 9,   // erfcx(a) - c*a*sum_n tbl_n
-    LC_MODE = 10,  // int[0]: 0: a<=0.1 ; 1: 0.1<a<7 ; 2: a>=7 or a<0 (generic path) ; 3: non-finite -> NaN
+    LC_K0 = 2,     // 14 wing coefficients  K_m = T*(a/sqrt(pi))*C_m(a^2)   (K0..K5 in the eager block)
+    // --- on demand ---
+    LC_D = 16,     // 1+z_tot  (as the reference rounds it)
+    LC_RD = 17,    // RN(1/(1+z_tot))
+    LC_CFD = 18,   // c_freq*(1+z_tot)
+    LC_FREQ0 = 19, // c_freq/lambda0
+    LC_IBF = 20,   // 1/b_f
+    LC_T = 21,     // (N*f)*constant
+    LC_Y = 22,     // a = gamma/(4 pi b_f)
+    LC_EA2 = 23,   // exp(a^2)
+    LC_MODE = 24,  // int[0]: 0: a<=0.1 ; 1: 0.1<a<7 ; 2: a>=7 or a<0 (generic path) ; 3: non-finite -> NaN
                    // int[1]: number of odd Taylor-in-a terms of the core series (mode 0)
-    LC_K0 = 11,    // 21 wing coefficients  K_m = T*(a/sqrt(pi))*C_m(a^2)
-    LC_TBL0 = 32,  // 26 entries  0.5*c*a*exp(-h^2 n^2)/(h^2 n^2 + a^2), n = 1..26
-    LC_EA2 = 58,   // exp(a^2)
+    LC_ACOS = 25,  // erfcx(a) - c*a*sum_n tbl_n                       (mode 1 only)
+    LC_TBL0 = 26,  // 26 entries  0.5*c*a*exp(-h^2 n^2)/(h^2 n^2 + a^2)  (mode 1 only)
 };
 
 constexpr double C_FREQ = 2.99792458e18;          // core/voigt_model.py:130
@@ -106,6 +108,30 @@ __device__ __forceinline__ double exp_neg(double t) {
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)n);
+}
+
+// Table-driven exp(-t), t >= 0: n = rint(-t * 64/ln2), r = -t - n ln2/64 (|r| <= 0.0054), result =
+// 2^(n>>6) * T[n&63] * (1 + r + ... + r^5/120).  T = 2^(j/64) staged in LDS (per-lane gather, 64
+// entries).  ~16 VALU instructions instead of ~45 for the polynomial version (whose 14 literal
+// coefficients each cost extra v_mov's); relative error ~2e-16.
+constexpr int EXP_LDS_DOUBLES = 64;
+__device__ __forceinline__ void exp_table_to_lds(double* __restrict__ et, int tid, int nthreads) {
+    for (int j = tid; j < EXP_LDS_DOUBLES; j += nthreads) et[j] = g_exp2_64[j];
+}
+__device__ __forceinline__ double exp_neg_tab(double t, const double* __restrict__ et) {
+    const double x = -fmin(t, 800.0);
+    const double n = __builtin_rint(x * INV_LN2_64);
+    double r = __builtin_fma(n, -LN2_64_HI, x);
+    r = __builtin_fma(n, -LN2_64_LO, r);
+    const int ni = (int)n;
+    const double tj = et[ni & 63];
+    double p = 8.33333333333333333333e-03;                 // 1/120
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(tj * p, ni >> 6);
 }
 
 // x as the reference rounds it (voigt_model.py:204,144,150) without divisions:
@@ -167,6 +193,16 @@ __device__ __forceinline__ double cos_small(double t) {
     return __builtin_fma(-p, t2, 1.0);
 }
 
+// cos(t) for |t| <= 0.1: five terms (t^10/10! < 3e-18)
+__device__ __forceinline__ double cos_tiny(double t) {
+    const double t2 = t * t;
+    double p = 2.4801587301587302e-05;                   //  1/8!
+    p = __builtin_fma(p, t2, -1.3888888888888889e-03);   // -1/6!
+    p = __builtin_fma(p, t2, 4.1666666666666667e-02);    //  1/4!
+    p = __builtin_fma(p, t2, -0.5);
+    return __builtin_fma(p, t2, 1.0);
+}
+
 __device__ __forceinline__ double sinc_safe(double t, double sint) {
     return fabs(t) < 1e-4 ? 1.0 - 0.1666666666666666666667 * t * t : sint / t;
 }
@@ -222,7 +258,8 @@ __device__ __forceinline__ void dawson_to_lds(double* __restrict__ daw, int tid,
     }
 }
 __device__ __forceinline__ double core_taylor_H_lds(double x, double a, double ea2, int nodd,
-                                                    const double* __restrict__ daw) {
+                                                    const double* __restrict__ daw,
+                                                    const double* __restrict__ et) {
     const double ax = fabs(x);
     const int i = min((int)(ax * 2.0), DAW_NI - 1);
     const double t = __builtin_fma(ax, 4.0, -(double)(2 * i + 1));
@@ -237,7 +274,7 @@ __device__ __forceinline__ double core_taylor_H_lds(double x, double a, double e
     }
     const double c = 1.1283791670955125739;          // 2/sqrt(pi)
     double vp = c * F, vc = c * G;                    // v_0, v_1
-    const double E = exp_neg(ax * ax);
+    const double E = exp_neg_tab(ax * ax, et);
     const double a2 = a * a;
     double apow = -a;
     double acc = apow * vc;
@@ -253,7 +290,9 @@ __device__ __forceinline__ double core_taylor_H_lds(double x, double a, double e
             acc = __builtin_fma(apow, vc, acc);
         }
     }
-    return __builtin_fma(E * ea2, cos_small(2.0 * a * ax), acc);
+    // 2 a |x| <= 16 a: a <= 5e-3 (nodd <= 3) keeps the argument below 0.08
+    const double cs = (nodd <= 3) ? cos_tiny(2.0 * a * ax) : cos_small(2.0 * a * ax);
+    return __builtin_fma(E * ea2, cs, acc);
 }
 
 // Core H(a,x), |x| < 7.2, 0 <= a < 7:  Alg. 916 real part

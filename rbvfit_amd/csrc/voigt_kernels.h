@@ -229,47 +229,11 @@ __device__ __forceinline__ double line_tau_wofz(const XP& xp, const double* __re
     return rec[LC_T] * generic_H(xf, rec, mode);
 }
 
-// ---------------------------------------------------------------------------------------------
-// A (walker,line) record held ACROSS THE LANES of one VGPR pair: lane k holds rec[k].  One
-// coalesced 512-B load per line and wave, prefetchable a line ahead; fields are pulled into SGPRs
-// with v_readlane (no scalar-memory round trips inside the line loop).
-// ---------------------------------------------------------------------------------------------
-struct LaneRec {
-    double v;
-    __device__ __forceinline__ double get(int k) const {      // k wave-uniform
-        const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-        return __hiloint2double(hi, lo);
-    }
-    __device__ __forceinline__ int mode() const { return __builtin_amdgcn_readlane(__double2loint(v), LC_MODE); }
-    __device__ __forceinline__ int nodd() const { return __builtin_amdgcn_readlane(__double2hiint(v), LC_MODE); }
-};
-
-__device__ __forceinline__ double faithful_x(double wave, double g, const LaneRec& R) {
-    const double d = R.get(LC_D), rd = R.get(LC_RD), cfd = R.get(LC_CFD);
-    double q0 = wave * rd;
-    double e = __builtin_fma(-q0, d, wave);
-    double wr = __builtin_fma(e, rd, q0);
-    double f0 = cfd * g;
-    double y0 = d * g;
-    double e2 = __builtin_fma(-f0, wr, C_FREQ);
-    double freq = __builtin_fma(e2, y0, f0);
-    return (freq - R.get(LC_FREQ0)) * R.get(LC_IBF);
-}
-
-template <int M>
-__device__ __forceinline__ double wing_tau(double x, const LaneRec& R) {
-    const double s = fast_rcp1(x * x);
-    double acc = R.get(LC_K0 + M - 1);
-#pragma unroll
-    for (int m = M - 2; m >= 0; --m) acc = __builtin_fma(acc, s, R.get(LC_K0 + m));
-    return acc * s;
-}
-
-// NOTE: LaneRec::get must only be used in wave-uniform control flow.  v_readlane reads lanes
-// regardless of EXEC, and inside a divergent branch the compiler is free to reuse the record's
-// VGPR in the lanes that are inactive there, so a cross-lane read would see clobbered data.
-// The cold path below therefore goes back to memory records through a scalarised pointer.
+// Line records are read with SCALAR loads (wave-uniform addresses): the fields land in SGPRs and
+// feed the fp64 VALU ops as scalar operands at no VALU cost.  (A previous version held the record
+// across the lanes of a VGPR and broadcast fields with v_readlane; measured at ~4.3 cycles each, the
+// readlanes were ~17 % of all VALU instructions, and a cross-lane read inside a divergent branch is
+// unsafe because the compiler may reuse the VGPR in the inactive lanes.)
 
 // Cold path of the tile kernel: one 64-pixel chunk of one line that touches the line core (or a
 // line outside the fast domain).  Out of line on purpose: it keeps the hot loop's registers and
@@ -300,23 +264,36 @@ constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span =
 #endif
 constexpr int RB = VP_RB;         // 64-pixel chunks per wave pass (register blocking / ILP)
 
-// s * Horner_M(K, s) for RB independent chunks with the same M; K from the lane-held record.
+// s * Horner_M(K, s) for RB independent chunks with the same M; K wave-uniform (SGPR operands).
 template <int M>
-__device__ __forceinline__ void wing_rb(const double (&x)[RB], const LaneRec& R, double (&tau)[RB]) {
+__device__ __forceinline__ void wing_rb(const double (&x)[RB], const double* __restrict__ K, double (&tau)[RB]) {
     double s[RB], acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) s[r] = fast_rcp1(x[r] * x[r]);
-    const double kt = R.get(LC_K0 + M - 1);
+    const double kt = K[M - 1];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = kt;
 #pragma unroll
     for (int m = M - 2; m >= 0; --m) {
-        const double km = R.get(LC_K0 + m);
+        const double km = K[m];
 #pragma unroll
         for (int r = 0; r < RB; ++r) acc[r] = __builtin_fma(acc[r], s[r], km);
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) tau[r] = __builtin_fma(acc[r], s[r], tau[r]);
+}
+
+// The eager block of a record: A, B, K0..K5 (one 64-byte scalar load) + mode.
+struct Eager {            // prefetched one line ahead: what the tier decision needs
+    double A, B;
+    int mode;
+};
+__device__ __forceinline__ Eager load_eager(const double* __restrict__ rec) {
+    Eager e;
+    e.A = rec[LC_A];
+    e.B = rec[LC_B];
+    e.mode = reinterpret_cast<const int*>(rec + LC_MODE)[0];
+    return e;
 }
 
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, ~77 VGPRs); it skips walkers
@@ -345,10 +322,12 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     const int TILE_THREADS = blockDim.x, nwaves = blockDim.x >> 6;
     double* __restrict__ daw = fl + I.span + 4;        // Dawson table for the line cores (16-B aligned)
     double* __restrict__ ktap = daw + DAW_LDS_DOUBLES; // LSF taps, read back as LDS broadcasts
-    unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(ktap + I.K);
+    double* __restrict__ etab = ktap + I.K;            // 2^(j/64) for the table-driven exp
+    unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(etab + EXP_LDS_DOUBLES);
     const int nwords = (I.L + 63) >> 6;                // 64 lines per mask word
     const int nchunks = (n_eval + 63) >> 6;
     for (int j = threadIdx.x; j < I.K; j += TILE_THREADS) ktap[j] = I.kflip[j];
+    exp_table_to_lds(etab, threadIdx.x, TILE_THREADS);
     if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
     if (GENERIC ? (gen == 0) : (gen != 0)) return;   // the other launch owns this walker
 
@@ -376,16 +355,18 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #pragma unroll
                 for (int r = 0; r < RB; ++r) todo[r] = 0ull;
                 const int l1 = min(I.L, l0 + 64);
-                double rec_next = lcw[(size_t)l0 * LC_STRIDE + lane];
+                Eager nxt = load_eager(lcw + (size_t)l0 * LC_STRIDE);
                 for (int l = l0; l < l1; ++l) {
-                    const LaneRec R{rec_next};
-                    rec_next = lcw[(size_t)min(l + 1, I.L - 1) * LC_STRIDE + lane];   // prefetch the next line
+                    const Eager cur = nxt;
+                    const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
+                    nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);   // scalar prefetch of the next line
                     const unsigned long long bit = 1ull << (l - l0);
-                    const double A = R.get(LC_A), B = R.get(LC_B);
+                    const double A = cur.A, B = cur.B;
+                    const double* __restrict__ K = rec + LC_K0;
                     double x[RB];
 #pragma unroll
                     for (int r = 0; r < RB; ++r) x[r] = __builtin_fma(A, g[r], -B);
-                    if (R.mode() != 0) {
+                    if (cur.mode != 0) {
 #pragma unroll
                         for (int r = 0; r < RB; ++r) todo[r] |= bit;
                         continue;
@@ -393,29 +374,35 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                     double xm = fabs(x[0]);
 #pragma unroll
                     for (int r = 1; r < RB; ++r) xm = fmin(xm, fabs(x[r]));
+#if defined(VP_ABLATE) && VP_ABLATE == 5
+                    { wing_rb<2>(x, K, tau); continue; }
+#endif
+#if defined(VP_ABLATE) && VP_ABLATE == 6
+                    { wing_rb<6>(x, K, tau); continue; }
+#endif
                     if (VP_NONE_BELOW(xm, 30.0)) {        // the 1-FMA x is accurate enough out here
                         if (VP_NONE_BELOW(xm, 100.0)) {
-                            if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, R, tau);
-                            else if (VP_NONE_BELOW(xm, 500.0)) wing_rb<3>(x, R, tau);
-                            else wing_rb<4>(x, R, tau);
+                            if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, K, tau);
+                            else if (VP_NONE_BELOW(xm, 500.0)) wing_rb<3>(x, K, tau);
+                            else wing_rb<4>(x, K, tau);
                         } else {
-                            wing_rb<6>(x, R, tau);
+                            wing_rb<6>(x, K, tau);
                         }
                         continue;
                     }
                     double xf[RB];
 #pragma unroll
-                    for (int r = 0; r < RB; ++r) xf[r] = faithful_x(wv[r], g[r], R);
-                    if (VP_NONE_BELOW(xm, 14.0)) { wing_rb<9>(xf, R, tau); continue; }
-                    if (VP_NONE_BELOW(xm, X_CORE)) { wing_rb<NWING>(xf, R, tau); continue; }
+                    for (int r = 0; r < RB; ++r) xf[r] = faithful_x(wv[r], g[r], rec);
+                    if (VP_NONE_BELOW(xm, 14.0)) { wing_rb<9>(xf, K, tau); continue; }
+                    if (VP_NONE_BELOW(xm, X_CORE)) { wing_rb<NWING>(xf, K, tau); continue; }
                     // some chunk of this wave touches the line core: flag it for phase B; the other
                     // chunks get their 14-term wing value here (wave-uniform branches)
 #pragma unroll
                     for (int r = 0; r < RB; ++r) {
 #if defined(VP_ABLATE) && VP_ABLATE == 1
-                        if (true) tau[r] += wing_tau<NWING>(xf[r], R);
+                        if (true) tau[r] += wing_tau<NWING>(xf[r], K);
 #else
-                        if (VP_NONE_BELOW(fabs(x[r]), X_CORE)) tau[r] += wing_tau<NWING>(xf[r], R);
+                        if (VP_NONE_BELOW(fabs(x[r]), X_CORE)) tau[r] += wing_tau<NWING>(xf[r], K);
                         else todo[r] |= bit;
 #endif
                     }
@@ -440,7 +427,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #if defined(VP_ABLATE) && VP_ABLATE == 3
             if (i < n_eval) fl[i] = pending[r] ? tau[r] : 1.0 - tau[r];
 #else
-            if (i < n_eval) fl[i] = pending[r] ? tau[r] : exp_neg(tau[r]);   // voigt_model.py:217
+            if (i < n_eval) fl[i] = pending[r] ? tau[r] : exp_neg_tab(tau[r], etab);   // voigt_model.py:217
 #endif
         }
     }
@@ -483,29 +470,28 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                     const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
                     m = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
                 }
-                double rec_next = m ? lcw[(size_t)((wd << 6) + __builtin_ctzll(m)) * LC_STRIDE + lane] : 0.0;
                 while (m) {
                     const int l = (wd << 6) + __builtin_ctzll(m);
                     m &= m - 1;
                     const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
-                    const LaneRec R{rec_next};
-                    if (m) rec_next = lcw[(size_t)((wd << 6) + __builtin_ctzll(m)) * LC_STRIDE + lane];   // prefetch
-                    if (R.mode() != 0) {
+                    const int mode = reinterpret_cast<const int*>(rec + LC_MODE)[0];
+                    if (mode != 0) {
                         if (GENERIC) tau += cold_line_tau(wq, gq, rec);
                         else tau = __builtin_nan("");          // poisoned line (non-finite constants)
                         continue;
                     }
-                    const double xf = faithful_x(wq, gq, R);
+                    const double xf = faithful_x(wq, gq, rec);
                     const double xa = fabs(xf);
-                    double h = R.get(LC_T) * core_taylor_H_lds(xf, R.get(LC_Y), R.get(LC_EA2), R.nodd(), daw);
+                    const int nodd = reinterpret_cast<const int*>(rec + LC_MODE)[1];
+                    double h = rec[LC_T] * core_taylor_H_lds(xf, rec[LC_Y], rec[LC_EA2], nodd, daw, etab);
                     if (__ballot(xa >= X_CORE) != 0ull) {
-                        const double rw = wing_tau<NWING>(xf, R);
+                        const double rw = wing_tau<NWING>(xf, rec + LC_K0);
                         h = (xa >= X_CORE) ? rw : h;
                     }
                     tau += h;
                 }
             }
-            if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg(tau);   // NaN survives (poisoned lines)
+            if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg_tab(tau, etab);   // NaN survives (poisoned lines)
         }
         __syncthreads();
     }
@@ -532,8 +518,18 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
             const double* fb[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) fb[r] = fl + min(idx[r], nout - 1);
-            for (int j = 0; j < kn; ++j) {
-                const double kj = ktap[j];                        // uniform address: LDS broadcast
+            int j = 0;
+            for (; j + 8 <= kn; j += 8) {                         // 8 taps per base-address update
+                const double* __restrict__ kb = ktap + j;         // uniform address: LDS broadcasts
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double kj = kb[u];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fb[r][j + u], m[r]);
+                }
+            }
+            for (; j < kn; ++j) {
+                const double kj = ktap[j];
 #pragma unroll
                 for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fb[r][j], m[r]);
             }
