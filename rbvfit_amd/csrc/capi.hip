@@ -29,6 +29,7 @@ struct Instrument {
     std::vector<double> h_lambda0, h_gamma;
     std::vector<int> h_bidx;
     bool needs_generic = true;
+    int nwaves = 1;              // waves per tile workgroup (1, 2 or 4)
 };
 
 }  // namespace
@@ -167,7 +168,7 @@ template <int OUT, bool GENERIC>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
                  int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag) {
     dim3 grid(W, in.dev.ntiles);
-    dim3 block(in.dev.span / 4 > 256 ? 256 : in.dev.span / 4);
+    dim3 block(64 * in.nwaves);
     if (in.dev.method == VP_VOIGT_FAST) {
         if (!GENERIC)
             hipLaunchKernelGGL((vp::tile_kernel<1, OUT, false>), grid, block, in.lds_bytes, s, in.dev, lc, flags, out,
@@ -356,27 +357,32 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     }
     std::vector<double> ginv(P);
     for (int p = 0; p < P; ++p) ginv[p] = 1.0 / wave[p];
-    double *d_wave, *d_ginv, *d_flux, *d_w, *d_k, *d_l0, *d_g, *d_f, *d_z;
+    double *d_wave, *d_ginv, *d_flux, *d_w, *d_k, *d_l0, *d_g, *d_f, *d_z, *d_fr0;
+    std::vector<double> freq0(L);
+    for (int l = 0; l < L; ++l) freq0[l] = vp::C_FREQ / lambda0[l];     // voigt_model.py:143
     int *d_n, *d_b, *d_v;
 #define UP(T, h, n, d) if ((rc = upload<T>(c, &in, h, n, &d))) { for (void* p : in.allocs) hipFree(p); return rc; }
     UP(double, wave, P, d_wave) UP(double, ginv.data(), P, d_ginv) UP(double, flux, P, d_flux) UP(double, inv_sigma2, P, d_w)
     UP(double, kflip.data(), kflip.size(), d_k)
-    UP(double, lambda0, L, d_l0) UP(double, gamma, L, d_g) UP(double, f, L, d_f) UP(double, zfac, L, d_z)
+    UP(double, lambda0, L, d_l0) UP(double, freq0.data(), L, d_fr0) UP(double, gamma, L, d_g) UP(double, f, L, d_f) UP(double, zfac, L, d_z)
     UP(int, N_idx, L, d_n) UP(int, b_idx, L, d_b) UP(int, v_idx, L, d_v)
 #undef UP
     in.d_flux = d_flux; in.d_w = d_w;
-    in.lines = vp::LinesDev{L, d_l0, d_g, d_f, d_z, d_n, d_b, d_v};
+    in.lines = vp::LinesDev{L, d_l0, d_fr0, d_g, d_f, d_z, d_n, d_b, d_v};
     vp::InstDev& d = in.dev;
     d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method;
     // Tile geometry: one wave evaluates 256 consecutive pixels (4 chunks of 64, register-blocked);
     // a workgroup is 1, 2 or 4 such waves.  Single-wave workgroups need no cross-wave barrier and
     // let the hardware balance the walkers' tiles; longer LSFs take wider tiles to keep the halo
     // (K-1 re-evaluated pixels per tile) a small fraction.
-    int span = Kuse <= 33 ? 256 : Kuse <= 65 ? 512 : 1024;
-    if (const char* sp = getenv("RBVFIT_AMD_SPAN")) span = atoi(sp);     // tuning experiments
-    if (Kuse > 257) span = std::min(8192, ((4 * Kuse + 63) / 64) * 64);
+    int nwaves = Kuse <= 33 ? 1 : Kuse <= 65 ? 2 : 4;
+    int span = 256 * nwaves;
+    if (const char* sp = getenv("RBVFIT_AMD_SPAN")) span = atoi(sp);     // tuning experiments (multiple of 64)
+    if (const char* nw = getenv("RBVFIT_AMD_WAVES")) nwaves = atoi(nw);
+    if (Kuse > 257) { span = std::min(8192, ((4 * Kuse + 63) / 64) * 64); nwaves = 4; }
     const int need = P + Kuse - 1;
-    if (need < span) span = std::max(256, ((need + 255) / 256) * 256);
+    if (need < span) span = std::max(64, ((need + 63) / 64) * 64);
+    in.nwaves = nwaves;
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;

@@ -25,6 +25,7 @@ namespace vp {
 struct LinesDev {          // static per-instrument line tables (CompiledModelData, voigt_model.py:265-280)
     int L;
     const double* lambda0;
+    const double* freq0;      // C_FREQ / lambda0 (IEEE quotient, formed on the host)
     const double* gamma;
     const double* f;
     const double* zfac;
@@ -119,7 +120,8 @@ __device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, 
         rec[LC_ACOS] = (mode == 1) ? erfcx(a) - (ALG916_C * a) * S1 : 0.0;
         reinterpret_cast<int*>(rec + LC_MODE)[0] = mode;
         reinterpret_cast<int*>(rec + LC_MODE)[1] = core_terms(a);
-        rec[LC_EA2] = exp(a2);
+        // exp(a^2): five Taylor terms in the fast domain (a <= 0.1, remainder 1e-22)
+        rec[LC_EA2] = (mode == 0) ? 1.0 + a2 * (1.0 + a2 * (0.5 + a2 * (1.0 / 6 + a2 * (1.0 / 24)))) : exp(a2);
     }
 }
 
@@ -146,30 +148,33 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
     }
     double* rec = lc + ((size_t)w * T.L + l) * LC_STRIDE;
     const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
-    const double N = pow(10.0, th[T.N_idx[l]]);        // :192
+    const double N = exp10(th[T.N_idx[l]]);            // :192  (10**theta; <= 1 ulp, only scales tau)
     const double b = th[T.b_idx[l]];                   // :193
     const double v = th[T.v_idx[l]];                   // :194
+    // quantities that enter x are formed with the reference's operations and roundings ...
     const double z_total = zf * (1.0 + v / C_KMS) - 1.0;   // :200
     const double d = 1.0 + z_total;                    // :204
     const double b_f = b / lam0 * 1e13;                // :142
-    const double freq0 = C_FREQ / lam0;                // :143
-    const double constant = ATOMIC_CONSTANT / (freq0 * b);   // :146
-    const double a = gam / (12.566370614359172 * b_f); // :149  (4*np.pi)
-    const double Tl = (N * fo) * constant;             // :158 (left-to-right)
-    const double cfd0 = C_FREQ * d;
-    const bool xok = (fabs(cfd0 / b_f) <= 1.79e308) && (fabs(freq0 / b_f) <= 1.79e308);
+    const double freq0 = T.freq0[l];                   // :143  C_FREQ / lambda0, IEEE quotient from the host
+    // ... the others only need ~1e-16 relative accuracy (reciprocal + Newton instead of IEEE division)
+    const double ibf = fast_rcp(b_f);
+    const double constant = ATOMIC_CONSTANT * fast_rcp(freq0 * b);   // :146
+    const double a = gam * (ibf * 0.079577471545947667884);          // :149  gamma / (4 pi b_f)
+    const double Tl = (N * fo) * constant;             // :158
+    const double cfd = C_FREQ * d;
+    const double Ax = cfd * ibf, Bx = freq0 * ibf;
+    const bool xok = (fabs(Ax) <= 1.79e308) && (fabs(Bx) <= 1.79e308);
     fill_record(rec, lane, xok ? Tl : __builtin_nan(""), a);
     // lines outside the fast domain (a > 0.1, a < 0): their walker goes to the generic kernel
     if (genflag && lane == 0 && (!(a >= 0.0) || a > 0.1) && (fabs(a) <= 1.79e308)) genflag[w] = 1;
     if (lane == 0) {
-        const double cfd = C_FREQ * d;
-        rec[LC_A] = cfd / b_f;
-        rec[LC_B] = freq0 / b_f;
+        rec[LC_A] = Ax;
+        rec[LC_B] = Bx;
         rec[LC_D] = d;
-        rec[LC_RD] = 1.0 / d;
+        rec[LC_RD] = 1.0 / d;                 // must be the correctly rounded reciprocal (faithful_x)
         rec[LC_CFD] = cfd;
         rec[LC_FREQ0] = freq0;
-        rec[LC_IBF] = 1.0 / b_f;
+        rec[LC_IBF] = ibf;
     }
 }
 
