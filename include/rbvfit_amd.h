@@ -108,6 +108,11 @@ int vp_model_flux_batch(vp_ctx* ctx, int inst, int W, int D, const double* theta
 int vp_model_flux_batch_device(vp_ctx* ctx, int inst, int W, int D, const double* d_theta,
                                double* d_out, int convolved, void* hip_stream);
 
+/* Per-line ("component") profiles.  Replaces: _evaluate_compiled_model(return_components=True)
+ * (core/voigt_model.py:232-259): out is row-major (W, L, P) host memory holding exp(-tau_l) of each
+ * line l, UNCONVOLVED -- exactly what the reference returns despite its comment (SURVEY trap T11). */
+int vp_model_flux_components(vp_ctx* ctx, int inst, int W, int D, const double* theta, double* out);
+
 /* H(a_i, x_j) = Re w(x_j + i a_i) on the device for a grid (host buffers; out is row-major
  * (na, nx)).  Test hook for the Faddeeva tiers that replace scipy.special.wofz at the call site
  * core/voigt_model.py:156: the production tier logic is used (tier chosen per wavefront = 64

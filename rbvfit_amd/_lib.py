@@ -46,6 +46,7 @@ SIGNATURES = {
     "vp_model_flux_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int]),
     "vp_model_flux_batch_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]),
+    "vp_model_flux_components": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "vp_voigt_h": (C.c_int, [_ctx, C.c_int, _dp, C.c_int, _dp, _dp]),
     "vp_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "vp_profile_read": (C.c_int, [_ctx, _dp, _dp, _dp, C.POINTER(C.c_int)]),

@@ -370,7 +370,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     in.d_flux = d_flux; in.d_w = d_w;
     in.lines = vp::LinesDev{L, d_l0, d_fr0, d_g, d_f, d_z, d_n, d_b, d_v};
     vp::InstDev& d = in.dev;
-    d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method;
+    d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method; d.line_sel = -1;
     // Tile geometry: one wave evaluates 256 consecutive pixels (4 chunks of 64, register-blocked);
     // a workgroup is 1, 2 or 4 such waves.  Single-wave workgroups need no cross-wave barrier and
     // let the hardware balance the walkers' tiles; longer LSFs take wider tiles to keep the halo
@@ -488,6 +488,39 @@ int vp_model_flux_batch(vp_ctx* c, int inst, int W, int D, const double* theta, 
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, (size_t)W * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* theta, double* out) {
+    int rc = check_batch_args(c, W, D, theta, out);
+    if (rc) return rc;
+    if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_components: instrument index out of range");
+    if (W == 0) return VP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, W))) return rc;
+    Instrument in = c->inst[inst];                 // local copy: line_sel is varied per launch
+    in.allocs.clear();
+    const size_t P = in.dev.P, L = in.dev.L;
+    if ((rc = ensure_scratch(c, (size_t)W * P * sizeof(double)))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
+    const bool gen = in.dev.method == VP_VOIGT_WOFZ;
+    if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
+    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, c->d_theta, W, c->D, in.lines, c->d_lb,
+                       c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr, gen ? c->d_genflag : (int*)nullptr);
+    const vp::FinalizeArgs nofin{};
+    const int* gf = gen ? c->d_genflag : (const int*)nullptr;
+    for (size_t l = 0; l < L; ++l) {
+        in.dev.line_sel = (int)l;
+        launch_tile<2, false>(in, c->d_lc, nullptr, c->d_scratch, (int)P, 0, W, s, nofin, gf);
+        if (gen) launch_tile<2, true>(in, c->d_lc, nullptr, c->d_scratch, (int)P, 0, W, s, nofin, gf);
+        HIP_TRY(c, hipGetLastError());
+        // (W, P) rows of line l -> out[w][l][:]
+        HIP_TRY(c, hipMemcpy2DAsync(out + l * P, L * P * sizeof(double), c->d_scratch, P * sizeof(double),
+                                    P * sizeof(double), W, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
     return VP_OK;
 }
 

@@ -1,22 +1,27 @@
 // HIP kernels of the Voigt lnprob path for gfx950 (MI355X).
 //
-// Data flow of one lnprob batch (W walkers, one instrument; instruments are launched back to back
-// on one stream and combined by finalize_kernel):
+// Data flow of one lnprob batch (W walkers; instruments are launched back to back on one stream):
 //
-//   prep_lines_kernel   grid W*L x 64 thr   theta row -> per-(walker,line) 512-B record (vp::LC_*)
-//                                           + box-prior flag per walker        (vfit_mcmc.py:291-295)
-//   tile_kernel         grid (tiles, W) x 256   one workgroup = one walker x one pixel tile:
-//                         tau(p) = sum_l tau_l(p)  (tiered H, voigt_device.h)  (voigt_model.py:207-214)
-//                         exp(-tau) -> LDS                                      (:217)
-//                         K-tap LSF from LDS, taps through scalar loads         (:220-230)
-//                         chi^2 term vs flux / inv_sigma2, wave+block reduce   (vfit_mcmc.py:309-311)
-//                         -> partial[w][tile]      (deterministic: no float atomics)
-//   finalize_kernel     grid ceil(W/256) x 256  sum partials in fixed order, add -0.5*(.. - sum log w),
-//                                           -inf for out-of-bounds walkers    (vfit_mcmc.py:348-353)
+//   prep_lines_kernel   grid W*L x 64 thr   theta row -> per-(walker,line) 512-B record (vp::LC_*),
+//                                           box-prior flag per walker + -inf rows (vfit_mcmc.py:291-295),
+//                                           optional flag for walkers with lines outside the fast domain
+//   tile_kernel         grid (W, tiles) x 64/128/256 thr   workgroup = walker x pixel tile
+//     phase A  tau(p) = sum_l tau_l(p) for every line >= 8 Doppler widths away  (voigt_model.py:207-214)
+//              lines outer loop, record fields by scalar loads (prefetched one line ahead), RB chunks
+//              of 64 pixels per wave pass with one tier per (line, wave pass)
+//     phase B  chunks that touch a line core: Taylor-in-a core series (Dawson tables in LDS)
+//     then     exp(-tau) (table-driven, LDS)                                  (:217)
+//              K-tap LSF from LDS, taps as LDS broadcasts                     (:220-230)
+//              chi^2 term vs flux / inv_sigma2, wave reduce -> partial[w][tile] (vfit_mcmc.py:309-311)
+//              last-arriving tile of a walker (agent-scope atomics) sums the partials in fixed order
+//              and writes lnprob = -0.5 (sum - sum log w)                      (vfit_mcmc.py:348-353)
+//   Two instances: GENERIC=false (no out-of-line generic Faddeeva, 79 VGPRs, 6 waves/SIMD) and
+//   GENERIC=true (handles walkers flagged by prep; launched only when the prior box allows a > 0.1).
 //
 // HBM layout: spectra (wave, 1/wave, flux, inv_sigma2) are 4 dense fp64 arrays per instrument,
 // read coalesced (8 B/lane) once per (walker, tile) and shared by all walkers through L2/MALL;
 // line records are read wave-uniformly (scalar loads, SGPR operands), never through VGPRs.
+// No float atomics anywhere: results are bit-reproducible.
 #pragma once
 #include "voigt_device.h"
 
@@ -52,6 +57,7 @@ struct InstDev {
     int TP;        // output pixels per tile = span - (K-1)
     int ntiles;
     int method;    // VP_VOIGT_*
+    int line_sel;  // -1: all lines; >= 0: only this line (per-line component flux)
     const double* wave;
     const double* ginv;    // RN(1/wave)
     const double* flux;
@@ -363,6 +369,10 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 Eager nxt = load_eager(lcw + (size_t)l0 * LC_STRIDE);
                 for (int l = l0; l < l1; ++l) {
                     const Eager cur = nxt;
+                    if (I.line_sel >= 0 && l != I.line_sel) {
+                        nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
+                        continue;
+                    }
                     const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
                     nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);   // scalar prefetch of the next line
                     const unsigned long long bit = 1ull << (l - l0);
@@ -421,6 +431,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
             }
         } else {
             for (int l = 0; l < I.L; ++l) {
+                if (I.line_sel >= 0 && l != I.line_sel) continue;
                 const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
 #pragma unroll
                 for (int r = 0; r < RB; ++r) tau[r] += line_tau_fast(PixelX{wv[r], g[r]}, rec);
@@ -585,23 +596,6 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
             }
         }
     }
-}
-
-// lnprob[w] = -inf if out of bounds else sum_inst -0.5 * (sum_tiles partial - sum log inv_sigma2)
-__global__ void finalize_kernel(const double* __restrict__ partial, int stride, const int* __restrict__ tile_off,
-                                const double* __restrict__ sum_logw, int n_inst,
-                                const int* __restrict__ flags, double* __restrict__ out, int W) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
-    if (flags[w]) { out[w] = -__builtin_inf(); return; }
-    const double* pw = partial + (size_t)w * stride;
-    double total = 0.0;
-    for (int k = 0; k < n_inst; ++k) {
-        double s = 0.0;
-        for (int t = tile_off[k]; t < tile_off[k + 1]; ++t) s += pw[t];
-        total += -0.5 * (s - sum_logw[k]);
-    }
-    out[w] = 0.0 + total;      // lp + lnlike (vfit_mcmc.py:353)
 }
 
 // Test hook: H(a_i, x_j) with the production tier logic (wave = 64 consecutive x_j of one a_i).

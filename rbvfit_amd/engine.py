@@ -154,6 +154,14 @@ class Engine:
                                                          C.c_void_p(d_theta_ptr), C.c_void_p(d_out_ptr),
                                                          1 if convolved else 0, C.c_void_p(stream_ptr)))
 
+    def model_flux_components(self, inst: int, theta, n_lines: int) -> np.ndarray:
+        """(W, L, P): unconvolved exp(-tau_l) of every line (the reference's ``components``)."""
+        self._guard()
+        th = self._theta2d(theta)
+        out = np.empty((th.shape[0], int(n_lines), self.n_pixels[inst]), dtype=np.float64)
+        self._check(self._lib.vp_model_flux_components(self._ctx, int(inst), th.shape[0], th.shape[1], _dp(th), _dp(out)))
+        return out
+
     def voigt_h(self, a, x) -> np.ndarray:
         """H(a_i, x_j) grid on the device (test hook for the Faddeeva tiers)."""
         self._guard()

@@ -218,6 +218,13 @@ class CompiledVoigtModel:
     def __call__(self, theta, wavelength):
         return self.model_flux(theta, wavelength)
 
+    def components(self, theta, wavelength) -> np.ndarray:
+        """Per-line unconvolved flux exp(-tau_l): (L, P) for one theta, (W, L, P) for a batch
+        (``_evaluate_compiled_model(..., return_components=True)['components']``, voigt_model.py:232-238)."""
+        theta = np.asarray(theta, dtype=np.float64)
+        out = self._engine_for(np.asarray(wavelength)).model_flux_components(0, theta, self.data.n_lines)
+        return out[0] if theta.ndim == 1 else out
+
     def __getstate__(self):
         raise TypeError("CompiledVoigtModel holds a GPU context and cannot be pickled; "
                         "run the sampler with use_pool=False (batched lnprob replaces the Pool)")

@@ -149,6 +149,33 @@ class vfit:
     def close(self):
         self.engine.close()
 
+    # -- batched finite-difference stencils -----------------------------------------
+    def lnprob_and_grad(self, theta, eps: float = 1e-8):
+        """lnprob(theta) and its forward-difference gradient from ONE batch of D+1 rows (the
+        stencil scipy's L-BFGS-B builds serially for the reference, vfit_mcmc.py:355-360).  Steps
+        that would leave the box are taken backwards."""
+        theta = np.asarray(theta, dtype=np.float64)
+        D = theta.size
+        h = np.where(theta + eps > self.ub, -eps, eps)
+        batch = np.vstack([theta[None, :], theta[None, :] + np.diag(h)])
+        lp = self.engine.lnprob(batch)
+        return float(lp[0]), (lp[1:] - lp[0]) / h
+
+    def optimize_guess(self, theta, eps: float = 1e-8):
+        """Mirror of ``vfit.optimize_guess`` (vfit_mcmc.py:355-360): L-BFGS-B on -lnprob inside the
+        bounds, with the finite-difference gradient evaluated as one GPU batch per iteration."""
+        import scipy.optimize as op
+
+        def nll(th):
+            f, g = self.lnprob_and_grad(th, eps)
+            if not np.isfinite(f):
+                return np.inf, np.zeros_like(th)
+            return -f, -g
+
+        res = op.minimize(nll, np.asarray(theta, dtype=np.float64), jac=True, method="L-BFGS-B",
+                          bounds=list(zip(self.lb, self.ub)))
+        return res.x
+
     # -- walker loop (host) ----------------------------------------------------------------------
     def runmcmc(self, optimize: bool = False, verbose: bool = False, use_pool: bool = False, seed=None):
         """Mirror of ``vfit.runmcmc`` (vfit_mcmc.py:492-561) reduced to the sampling itself: walker

@@ -207,3 +207,40 @@ def test_engine_argument_errors():
             e.lnprob(np.zeros((3, 5)))
         assert e.lnprob(np.zeros((0, 6))).shape == (0,)      # empty batch
         np.testing.assert_allclose(e.lnprob(z["thetas"])[:4], z["lnprob"][:4], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+
+
+def test_components_and_batched_gradient():
+    """'Next' rows N3 (per-line unconvolved profiles, voigt_model.py:232-259) and N2 (batched
+    finite-difference stencil for optimize_guess, vfit_mcmc.py:355-360)."""
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    from rbvfit_amd.vfit import vfit
+    z = load_golden("c0_mgii")
+    cfg = FitConfiguration(); cfg.add_system(0.348, "MgII", [2796.35, 2803.53], 2)
+    model = VoigtModel(cfg, FWHM="6.5")
+    cm = model.compile()
+    th = z["thetas"][:3]
+    comp = cm.components(th, z["G__wave"])
+    assert comp.shape == (3, 4, 4096)
+    data = vo.data_from_fixture(z, "G")
+    for i in range(3):
+        t = th[i]
+        N = 10 ** t[data.N_indices]; b = t[data.b_indices]; v = t[data.v_indices]
+        zt = data.z_factors * (1 + v / 299792.458) - 1
+        wr = z["G__wave"][None, :] / (1 + zt[:, None])
+        tau = vo.voigt_tau(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, N, b, wr)
+        np.testing.assert_allclose(comp[i], np.exp(-tau), rtol=0, atol=FLUX_ATOL)
+        np.testing.assert_allclose(np.prod(comp[i], axis=0), cm.model_flux(t, z["G__wave"], convolved=False), rtol=0, atol=1e-12)
+    inst = {"G": {"model": model, "wave": z["G__wave"], "flux": z["G__flux"], "error": z["G__error"]}}
+    fit = vfit(inst, z["theta_true"], z["lb"], z["ub"])
+    try:
+        t0 = z["thetas"][1]
+        f, g = fit.lnprob_and_grad(t0)
+        singles = np.array([(fit.lnprob(t0 + 1e-8 * np.eye(6)[k]) - fit.lnprob(t0)) / 1e-8 for k in range(6)])
+        assert f == fit.lnprob(t0)
+        np.testing.assert_allclose(g, singles, rtol=0, atol=0)                  # same stencil, one batch
+        best = fit.optimize_guess(t0)
+        assert np.all(best >= z["lb"]) and np.all(best <= z["ub"])
+        assert fit.lnprob(best) >= fit.lnprob(t0)
+    finally:
+        fit.close()
