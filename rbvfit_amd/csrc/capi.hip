@@ -45,7 +45,7 @@ struct vp_ctx {
     std::vector<Instrument> inst;
     // per-batch workspace (grown on demand)
     int capW = 0;
-    int capL = 0;          // max lines over instruments the workspace was sized for
+    int capL = 0;          // max records per walker (lines + multipole clusters) the workspace was sized for
     int cap_tiles = 0;
     double* d_theta = nullptr;   // (capW, D)
     double* d_out = nullptr;     // (capW)
@@ -126,7 +126,7 @@ int ensure_pinned(vp_ctx* c, size_t bytes) {
 
 int ensure_workspace(vp_ctx* c, int W) {
     int maxL = 1;
-    for (auto& in : c->inst) maxL = std::max(maxL, in.dev.L);
+    for (auto& in : c->inst) maxL = std::max(maxL, in.dev.L + in.dev.NCm);
     if (c->meta_dirty) {
         std::vector<int> off(c->inst.size() + 1, 0);
         std::vector<double> slw(c->inst.size() + 1, 0.0);
@@ -215,7 +215,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
         if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-        hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines,
+        hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * (in.dev.L + in.dev.NCm)), dim3(64), 0, s, d_theta, W, c->D, in.lines,
                            c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr);
         size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin,
@@ -366,11 +366,32 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     UP(double, kflip.data(), kflip.size(), d_k)
     UP(double, lambda0, L, d_l0) UP(double, freq0.data(), L, d_fr0) UP(double, gamma, L, d_g) UP(double, f, L, d_f) UP(double, zfac, L, d_z)
     UP(int, N_idx, L, d_n) UP(int, b_idx, L, d_b) UP(int, v_idx, L, d_v)
-#undef UP
     in.d_flux = d_flux; in.d_w = d_w;
-    in.lines = vp::LinesDev{L, d_l0, d_fr0, d_g, d_f, d_z, d_n, d_b, d_v};
+    // multipole clusters: maximal runs of >= 3 (and <= 64) consecutive lines with the same rest
+    // wavelength and redshift factor = the components of one transition (voigt_model.py:391-401)
+    std::vector<int> cl_mp(L, -1), cl_end(L, 0), cl_first, cl_count;
+    for (int l = 0; l < L;) {
+        int e = l + 1;
+        while (e < L && lambda0[e] == lambda0[l] && zfac[e] == zfac[l]) ++e;
+        for (int k = l; k < e; ++k) cl_end[k] = e;
+        const bool enable = !getenv("RBVFIT_AMD_NO_MULTIPOLE");
+        // (two lines cost about as much as one 13-term expansion: only clusters of >= 3 pay off)
+        if (enable && e - l >= 3 && e - l <= 64 && voigt_method == VP_VOIGT_WOFZ) {
+            cl_mp[l] = (int)cl_first.size();
+            cl_first.push_back(l);
+            cl_count.push_back(e - l);
+        }
+        l = e;
+    }
+    const int NCm = (int)cl_first.size();
+    int *d_clmp, *d_clend, *d_clfirst, *d_clcount;
+    UP(int, cl_mp.data(), L, d_clmp) UP(int, cl_end.data(), L, d_clend)
+    UP(int, cl_first.data(), cl_first.size(), d_clfirst) UP(int, cl_count.data(), cl_count.size(), d_clcount)
+    in.lines = vp::LinesDev{L, d_l0, d_fr0, d_g, d_f, d_z, d_n, d_b, d_v, NCm, d_clfirst, d_clcount};
     vp::InstDev& d = in.dev;
     d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method; d.line_sel = -1;
+    d.NCm = NCm; d.cl_mp = d_clmp; d.cl_end = d_clend;
+#undef UP
     // Tile geometry: one wave evaluates 256 consecutive pixels (4 chunks of 64, register-blocked);
     // a workgroup is 1, 2 or 4 such waves.  Single-wave workgroups need no cross-wave barrier and
     // let the hardware balance the walkers' tiles; longer LSFs take wider tiles to keep the halo
@@ -455,7 +476,7 @@ int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* 
     const Instrument& in = c->inst[inst];
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;      // model_flux has no prior box: theta may be anything
     if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, d_theta, W, c->D, in.lines, c->d_lb,
+    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * (in.dev.L + in.dev.NCm)), dim3(64), 0, s, d_theta, W, c->D, in.lines, c->d_lb,
                        c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr, gen ? c->d_genflag : (int*)nullptr);
     const vp::FinalizeArgs nofin{};
     const int* gf = gen ? c->d_genflag : (const int*)nullptr;
@@ -507,7 +528,7 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;
     if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * in.dev.L), dim3(64), 0, s, c->d_theta, W, c->D, in.lines, c->d_lb,
+    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * (in.dev.L + in.dev.NCm)), dim3(64), 0, s, c->d_theta, W, c->D, in.lines, c->d_lb,
                        c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr, gen ? c->d_genflag : (int*)nullptr);
     const vp::FinalizeArgs nofin{};
     const int* gf = gen ? c->d_genflag : (const int*)nullptr;

@@ -37,6 +37,10 @@ struct LinesDev {          // static per-instrument line tables (CompiledModelDa
     const int* N_idx;
     const int* b_idx;
     const int* v_idx;
+    // multipole clusters (components of one transition): first line and member count per cluster
+    int NCm;
+    const int* cl_first;
+    const int* cl_count;
 };
 
 struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of a walker)
@@ -58,6 +62,9 @@ struct InstDev {
     int ntiles;
     int method;    // VP_VOIGT_*
     int line_sel;  // -1: all lines; >= 0: only this line (per-line component flux)
+    int NCm;       // number of multipole clusters (records follow the line records of a walker)
+    const int* cl_mp;      // per line: cluster index if the line is the FIRST of a multipole cluster, else -1
+    const int* cl_end;     // per line: one past the last line of its cluster
     const double* wave;
     const double* ginv;    // RN(1/wave)
     const double* flux;
@@ -69,6 +76,12 @@ struct InstDev {
 // compile-time table of the wing-series polynomials  C_m(a^2) = sum_i WC[m][i] a^(2i)
 //   WC[m][i] = binom(2m+1, 2i+1) (-1)^i (2(m-i)-1)!! / 2^(m-i)
 // ---------------------------------------------------------------------------------------------
+// Multipole record of a cluster (same 64-double stride as a line record):
+//   [0] A_c  [1] B_c  (y = A_c/wave - B_c)   [2] Yfar (use the expansion when every |y| >= Yfar)
+//   [3..15] Q_2..Q_14 :  tau_cluster(y) = sum_j Q_j y^-j
+constexpr int MP_A = 0, MP_B = 1, MP_YFAR = 2, MP_Q0 = 3, MP_NQ = 13, MP_JMIN = 2;
+constexpr int MP_MWING = 4;      // asymptotic terms kept per member (valid for |x| >= 100)
+
 struct WingTable { double c[NWING][NWING]; };
 constexpr WingTable make_wing_table() {
     WingTable t{};
@@ -131,6 +144,92 @@ __device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, 
     }
 }
 
+// Multipole expansion of one cluster (the components of one transition) about its centre, for the
+// pixels that are far from all of its members:  with y = A_c/wave - B_c and x_l = alpha_l (y + delta_l),
+//   sum_l sum_{m<4} K_{l,m} x_l^(-2m-2)  =  sum_{j=2..14} Q_j y^-j,
+//   Q_j = sum_l sum_{n=2m+2<=j} K_{l,m} alpha_l^-n (-1)^(j-n) C(j-1, n-1) delta_l^(j-n).
+// A_c is the smallest A_l of the cluster (alpha_l >= 1), B_c centres the delta_l.  The record is used
+// only where every |y| >= Yfar = max(100 + max|delta|, 10 max|delta|): there each member is in its
+// 4-term asymptotic regime (|x_l| >= 100) and the expansion ratio is <= 0.1 (truncation < 2e-12 of
+// an already tiny far-wing tau).  Lane l' handles member l'; 64-thread wave.
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ void prep_cluster(const double* __restrict__ th, const LinesDev& T, int k,
+                                             double* __restrict__ rec, int lane) {
+    const int first = T.cl_first[k], n = T.cl_count[k];
+    const bool mem = lane < n;
+    const int l = first + (mem ? lane : 0);
+    const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
+    const double N = exp10(th[T.N_idx[l]]);
+    const double b = th[T.b_idx[l]], v = th[T.v_idx[l]];
+    const double d = 1.0 + (zf * (1.0 + v / C_KMS) - 1.0);
+    const double b_f = b / lam0 * 1e13;
+    const double freq0 = T.freq0[l];
+    const double ibf = fast_rcp(b_f);
+    const double a = gam * (ibf * 0.079577471545947667884);
+    const double Tl = (N * fo) * (ATOMIC_CONSTANT * fast_rcp(freq0 * b));
+    const double A = (C_FREQ * d) * ibf, B = freq0 * ibf;
+    const bool ok = (a >= 0.0) && (a <= 0.1) && (fabs(Tl) <= 1.79e308) && (fabs(A) <= 1.79e308) && (fabs(B) <= 1.79e308)
+                    && (A > 0.0);
+    const int allok = __all(ok || !mem);
+    const double Ac = wave_min(mem ? A : 1.79e308);
+    const double g0 = B * fast_rcp(A);                         // line centre in 1/wave units
+    const double g0c = wave_sum(mem ? g0 : 0.0) / (double)n;
+    const double Bc = Ac * g0c;
+    const double alpha = A * fast_rcp(Ac);                      // >= 1
+    const double delta = Ac * (g0c - g0);                       // x_l = alpha (y + delta)
+    const double dmax = wave_max(mem ? fabs(delta) : 0.0);
+    // member's wing coefficients K_m, m < 4, divided by alpha^(2m+2)
+    double Km[MP_MWING];
+    {
+        const double a2 = a * a, pref = Tl * (a * INV_SQRT_PI);
+        const double ia2 = fast_rcp(alpha * alpha);
+        double ipow = ia2;
+#pragma unroll
+        for (int m = 0; m < MP_MWING; ++m) {
+            double cm = 0.0;
+            for (int i = m; i >= 0; --i) cm = __builtin_fma(cm, a2, g_wing.c[m][i]);
+            Km[m] = mem ? pref * cm * ipow : 0.0;
+            ipow *= ia2;
+        }
+    }
+    // Q_j, j = 2..14
+    double dpow[MP_NQ + 1];                                     // (-delta)^k, k = 0..13
+    dpow[0] = 1.0;
+#pragma unroll
+    for (int kk = 1; kk <= MP_NQ; ++kk) dpow[kk] = dpow[kk - 1] * (-delta);
+#pragma unroll
+    for (int jq = 0; jq < MP_NQ; ++jq) {
+        const int j = jq + MP_JMIN;
+        double q = 0.0;
+#pragma unroll
+        for (int m = 0; m < MP_MWING; ++m) {
+            const int nn = 2 * m + 2;
+            if (nn <= j) {
+                // C(j-1, nn-1)
+                double binom = 1.0;
+                for (int t = 1; t <= nn - 1; ++t) binom = binom * (double)(j - 1 - (nn - 1) + t) / (double)t;
+                q = __builtin_fma(Km[m] * binom, dpow[j - nn], q);
+            }
+        }
+        q = wave_sum(q);
+        if (lane == 0) rec[MP_Q0 + jq] = q;
+    }
+    if (lane == 0) {
+        rec[MP_A] = Ac;
+        rec[MP_B] = Bc;
+        rec[MP_YFAR] = allok ? fmax(100.0 + dmax, 10.0 * dmax) : __builtin_inf();   // inf: never use the expansion
+    }
+}
+
 // One 64-thread workgroup per (walker, line).  Follows _evaluate_compiled_model's scalar prologue
 // (voigt_model.py:192-200) and _vectorized_voigt_tau's per-line constants (:142-149) operation by
 // operation (the file is compiled with -ffp-contract=off, so nothing here is fused).
@@ -140,9 +239,14 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
                                                         double* __restrict__ lc, int* __restrict__ flags,
                                                         int do_flags, double* __restrict__ lnprob_out,
                                                         int* __restrict__ genflag) {
-    const int w = blockIdx.x / T.L, l = blockIdx.x % T.L;
+    const int nrec = T.L + T.NCm;                     // records per walker: lines, then clusters
+    const int w = blockIdx.x / nrec, l = blockIdx.x % nrec;
     const int lane = threadIdx.x;
     const double* th = theta + (size_t)w * D;
+    if (l >= T.L) {                                   // ---- multipole record of one cluster ----
+        prep_cluster(th, T, l - T.L, lc + ((size_t)w * nrec + l) * LC_STRIDE, lane);
+        return;
+    }
     if (do_flags && l == 0) {
         int oob = 0;
         for (int d = lane; d < D; d += 64) oob |= (th[d] < lb[d]) || (th[d] > ub[d]);   // vfit_mcmc.py:293
@@ -152,7 +256,7 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
             if (any && lnprob_out) lnprob_out[w] = -__builtin_inf();   // vfit_mcmc.py:350-351
         }
     }
-    double* rec = lc + ((size_t)w * T.L + l) * LC_STRIDE;
+    double* rec = lc + ((size_t)w * nrec + l) * LC_STRIDE;
     const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
     const double N = exp10(th[T.N_idx[l]]);            // :192  (10**theta; <= 1 ulp, only scales tau)
     const double b = th[T.b_idx[l]];                   // :193
@@ -328,7 +432,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     const int nout = p1 - p0;
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
-    const double* __restrict__ lcw = lc + (size_t)w * I.L * LC_STRIDE;
+    const double* __restrict__ lcw = lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int TILE_THREADS = blockDim.x, nwaves = blockDim.x >> 6;
     double* __restrict__ daw = fl + I.span + 4;        // Dawson table for the line cores (16-B aligned)
@@ -360,7 +464,11 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
         bool pending[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) pending[r] = false;
+#if defined(VP_ABLATE) && VP_ABLATE == 7
+        if (false) {
+#else
         if (METHOD == 0) {
+#endif
             for (int l0 = 0; l0 < I.L; l0 += 64) {
                 unsigned long long todo[RB];
 #pragma unroll
@@ -368,6 +476,35 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 const int l1 = min(I.L, l0 + 64);
                 Eager nxt = load_eager(lcw + (size_t)l0 * LC_STRIDE);
                 for (int l = l0; l < l1; ++l) {
+                    // far from a whole cluster of components?  one multipole evaluation replaces all of
+                    // its member lines (only tried at the first line of a cluster that fits this block)
+                    const int mp = (I.NCm > 0 && I.line_sel < 0) ? I.cl_mp[l] : -1;
+                    if (mp >= 0 && I.cl_end[l] <= l1) {
+                        const double* __restrict__ mrec = lcw + (size_t)(I.L + mp) * LC_STRIDE;
+                        const double Ac = mrec[MP_A], Bc = mrec[MP_B], yfar = mrec[MP_YFAR];
+                        double y[RB];
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) y[r] = __builtin_fma(Ac, g[r], -Bc);
+                        double ym = fabs(y[0]);
+#pragma unroll
+                        for (int r = 1; r < RB; ++r) ym = fmin(ym, fabs(y[r]));
+                        if (__ballot(!(ym >= yfar)) == 0ull) {      // every lane far enough (NaN counts as near)
+                            double q[RB], acc[RB];
+#pragma unroll
+                            for (int r = 0; r < RB; ++r) { q[r] = fast_rcp1(y[r]); acc[r] = mrec[MP_Q0 + MP_NQ - 1]; }
+#pragma unroll
+                            for (int jq = MP_NQ - 2; jq >= 0; --jq) {
+                                const double qj = mrec[MP_Q0 + jq];
+#pragma unroll
+                                for (int r = 0; r < RB; ++r) acc[r] = __builtin_fma(acc[r], q[r], qj);
+                            }
+#pragma unroll
+                            for (int r = 0; r < RB; ++r) tau[r] = __builtin_fma(acc[r], q[r] * q[r], tau[r]);
+                            l = I.cl_end[l] - 1;                       // skip the member lines
+                            nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
+                            continue;
+                        }
+                    }
                     const Eager cur = nxt;
                     if (I.line_sel >= 0 && l != I.line_sel) {
                         nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
@@ -429,7 +566,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                     if (lane == 0 && c < nchunks) cmask[c * nwords + (l0 >> 6)] = todo[r];
                 }
             }
-        } else {
+        } else if (METHOD == 1) {
             for (int l = 0; l < I.L; ++l) {
                 if (I.line_sel >= 0 && l != I.line_sel) continue;
                 const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
@@ -526,7 +663,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #pragma unroll
             for (int r = 0; r < RB; ++r) m[r] = fl[min(idx[r], nout - 1) + I.halo_lo];
         } else {
-#if defined(VP_ABLATE) && VP_ABLATE == 2
+#if defined(VP_ABLATE) && (VP_ABLATE == 2 || VP_ABLATE == 7)
             const int kn = 1;
 #else
             const int kn = I.K;
