@@ -3,6 +3,7 @@
 from ._lib import (RbvfitAmdError, RbvfitAmdLibraryError, LSF_NONE, LSF_SCIPY_NEAREST,
                    LSF_ASTROPY_EXTEND, VOIGT_WOFZ, VOIGT_FAST, LIB_PATH)
 from .engine import Engine, device_count
+from . import model, vfit, sampler, dist, lsf, atomic, workloads, cog  # noqa: F401  (host mirror of the reference interface)
 
 __version__ = "0.1.0"
 __all__ = ["Engine", "device_count", "RbvfitAmdError", "RbvfitAmdLibraryError", "LIB_PATH",

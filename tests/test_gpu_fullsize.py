@@ -244,3 +244,20 @@ def test_components_and_batched_gradient():
         assert fit.lnprob(best) >= fit.lnprob(t0)
     finally:
         fit.close()
+
+
+def test_curve_of_growth_grid_is_one_batch():
+    """'Next' row N4 (compute_cog.py:23-183): EW(N, b) for HI Lya vs the oracle, incl. the damped regime."""
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.cog import compute_cog
+    Nlist, blist = np.linspace(12.0, 21.0, 19), [5.0, 20.0, 60.0]
+    cog = compute_cog(1215.67, Nlist, blist)
+    assert cog.Wlist.shape == (19, 3) and cog.st["name"] == "HI 1215"
+    d = vo.OracleModelData(np.array([1215.6701]), np.array([6.265e8], dtype=np.float32), np.array([0.4164], dtype=np.float32),
+                           np.array([1.0]), np.array([0]), np.array([1]), np.array([2]), np.zeros(0), 0)
+    trap = getattr(np, "trapezoid", None) or np.trapz
+    for i in (0, 7, 13, 18):
+        for j in range(3):
+            fl = vo.model_flux(d, np.array([Nlist[i], blist[j], 0.0]), cog.wave)
+            assert abs(cog.Wlist[i, j] - trap(1 - fl, x=cog.wave)) < 1e-11
+    assert np.all(np.diff(cog.Wlist, axis=0) > 0)            # EW grows with N
