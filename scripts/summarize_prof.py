@@ -40,7 +40,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
 
 # machine-readable traffic figure for bench.py (tile kernel, lnprob variant)
 import json
-def mean_counter(sub, counter, kernel_sub="tile_kernel<0, 0>"):
+def mean_counter(sub, counter, kernel_sub="tile_kernel<0, 0"):
     vals = []
     for f in find(sub, "*counter_collection.csv"):
         with open(f) as fh:
