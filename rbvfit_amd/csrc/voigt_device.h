@@ -252,9 +252,18 @@ __device__ __forceinline__ double core_taylor_H(double x, double a, double ea2, 
 // degree); used by the tile kernel's hot loop.
 constexpr int DAW_LDS_DOUBLES = DAW_NI * 2 * (DAW_DEG + 1);
 __device__ __forceinline__ void dawson_to_lds(double* __restrict__ daw, int tid, int nthreads) {
-    for (int idx = tid; idx < DAW_LDS_DOUBLES; idx += nthreads) {
+    // all loads first, then all LDS writes (one memory round trip); 448 entries, >= 64 threads
+    double v[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int idx = min(tid + u * nthreads, DAW_LDS_DOUBLES - 1);
         const int i = idx / (2 * (DAW_DEG + 1)), rem = idx % (2 * (DAW_DEG + 1));
-        daw[idx] = g_dawson[i][rem & 1][rem >> 1];
+        v[u] = g_dawson[i][rem & 1][rem >> 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int idx = tid + u * nthreads;
+        if (idx < DAW_LDS_DOUBLES) daw[idx] = v[u];
     }
 }
 __device__ __forceinline__ double core_taylor_H_lds(double x, double a, double ea2, int nodd,

@@ -441,10 +441,24 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(etab + EXP_LDS_DOUBLES);
     const int nwords = (I.L + 63) >> 6;                // 64 lines per mask word
     const int nchunks = (n_eval + 63) >> 6;
-    for (int j = threadIdx.x; j < I.K; j += TILE_THREADS) ktap[j] = I.kflip[j];
-    exp_table_to_lds(etab, threadIdx.x, TILE_THREADS);
+    // Put every independent load of the prologue in flight before the first wait: LSF taps, exp table,
+    // the first pass's pixel data (the flag loads above are scalar).  A wave's start-up is then one
+    // memory round trip instead of four.
+    const double tap_pre = I.kflip[min((int)threadIdx.x, I.K - 1)];
+    const double exp_pre = g_exp2_64[threadIdx.x & 63];
+    double g_pre[RB], wv_pre[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int i = min(wid * (64 * RB) + r * 64 + lane, n_eval - 1);
+        const int q = min(max(q0 + i, 0), I.P - 1);
+        g_pre[r] = I.ginv[q];
+        wv_pre[r] = I.wave[q];
+    }
     if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
     if (GENERIC ? (gen == 0) : (gen != 0)) return;   // the other launch owns this walker
+    if ((int)threadIdx.x < I.K) ktap[threadIdx.x] = tap_pre;
+    for (int j = threadIdx.x + TILE_THREADS; j < I.K; j += TILE_THREADS) ktap[j] = I.kflip[j];
+    if (threadIdx.x < EXP_LDS_DOUBLES) etab[threadIdx.x] = exp_pre;
 
     // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
     //      Each wave owns 256 consecutive evaluated pixels per pass (RB chunks of 64); lines are the
@@ -453,13 +467,18 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     //      flagged; their tau goes to LDS raw and phase B finishes them.
     for (int base = wid * (64 * RB); base < n_eval; base += TILE_THREADS * RB) {
         double g[RB], wv[RB], tau[RB];
+        if (base == wid * (64 * RB)) {                    // first pass: loaded in the prologue
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int i = min(base + r * 64 + lane, n_eval - 1);
-            const int q = min(max(q0 + i, 0), I.P - 1);   // edge replication = evaluate the clamped pixel
-            g[r] = I.ginv[q];
-            wv[r] = I.wave[q];
-            tau[r] = 0.0;
+            for (int r = 0; r < RB; ++r) { g[r] = g_pre[r]; wv[r] = wv_pre[r]; tau[r] = 0.0; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int i = min(base + r * 64 + lane, n_eval - 1);
+                const int q = min(max(q0 + i, 0), I.P - 1);   // edge replication = evaluate the clamped pixel
+                g[r] = I.ginv[q];
+                wv[r] = I.wave[q];
+                tau[r] = 0.0;
+            }
         }
         bool pending[RB];
 #pragma unroll
