@@ -53,6 +53,7 @@ struct vp_ctx {
     double* d_partial = nullptr; // (capW, total_tiles)
     int* d_flags = nullptr;      // (capW)
     unsigned int* d_ticket = nullptr;  // (capW) arrival counters of the fused final reduction
+    unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int* d_genflag = nullptr;    // (capW) walkers with lines outside the fast domain (per instrument pass)
     std::vector<double> h_lb;    // host copy of the lower bounds
     int* d_tile_off = nullptr;   // (n_inst + 1)
@@ -210,7 +211,8 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     int tile_off = 0;
     const bool prof = c->profiling;
     size_t m0 = prof ? prof_mark(c, s) : 0;
-    const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off, c->d_sum_logw, d_out, (int)c->inst.size(), c->total_tiles};
+    const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off, c->d_sum_logw, d_out, (int)c->inst.size(), c->total_tiles,
+                               c->d_stamps};
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
@@ -598,6 +600,20 @@ int vp_profile_read(vp_ctx* c, double* prep_ms, double* tile_ms, double* finaliz
     c->spans.clear();
     return VP_OK;
 }
+
+#ifdef VP_STAMP
+// diagnostic build only (scripts/stamps.py): allocate the stamp buffer for n workgroups / copy it back
+extern "C" int vp_debug_stamps_alloc(vp_ctx* c, int n) {
+    if (c->d_stamps) hipFree(c->d_stamps);
+    if (hipMalloc((void**)&c->d_stamps, (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    hipMemset(c->d_stamps, 0, (size_t)n * 8 * sizeof(unsigned long long));
+    return 0;
+}
+extern "C" int vp_debug_stamps_read(vp_ctx* c, int n, unsigned long long* out) {
+    hipDeviceSynchronize();
+    return hipMemcpy(out, c->d_stamps, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+#endif
 
 int vp_num_instruments(const vp_ctx* c) { return c ? (int)c->inst.size() : 0; }
 int vp_ndim(const vp_ctx* c) { return c ? c->D : 0; }

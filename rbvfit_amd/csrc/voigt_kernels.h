@@ -50,6 +50,7 @@ struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of 
     double* lnprob;              // (W) output
     int n_inst;
     int total_tiles;             // arrivals per walker over all instruments
+    unsigned long long* stamps;  // diagnostic builds (-DVP_STAMP): 8 time stamps per workgroup, else unused
 };
 
 struct InstDev {
@@ -425,6 +426,9 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     // walkers are the fast grid dimension and the (short) last tile comes last, so the tail of the
     // launch is filled with the cheapest workgroups
     const int t = blockIdx.y, w = blockIdx.x;
+#ifdef VP_STAMP
+    unsigned long long st0 = __builtin_amdgcn_s_memrealtime(), st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+#endif
     const int oob = (OUT == 0) ? flags[w] : 0;   // tested below, after the first loads are in flight
     const int gen = genflag ? genflag[w] : 0;
     const int p0 = t * I.TP;
@@ -460,6 +464,9 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     for (int j = threadIdx.x + TILE_THREADS; j < I.K; j += TILE_THREADS) ktap[j] = I.kflip[j];
     if (threadIdx.x < EXP_LDS_DOUBLES) etab[threadIdx.x] = exp_pre;
 
+#ifdef VP_STAMP
+    st1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
     //      Each wave owns 256 consecutive evaluated pixels per pass (RB chunks of 64); lines are the
     //      outer loop so that a line's constants are fetched once and feed RB independent
@@ -605,6 +612,9 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     }
     __syncthreads();
 
+#ifdef VP_STAMP
+    st2 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- phase B: line cores.  The flagged chunks of the tile are dealt round-robin to the four
     //      waves (balanced whatever their position), each chunk finished by one wave: core series
     //      for every lane (no divergence), 14-term wing value for lanes of a mixed chunk beyond the
@@ -668,6 +678,9 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
         __syncthreads();
     }
 
+#ifdef VP_STAMP
+    st3 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- LSF from LDS (taps broadcast from lanes), chi^2 term, reduce -----------------------------
     double acc = 0.0;
     for (int ib = 0; ib < nout; ib += TILE_THREADS * RB) {
@@ -719,6 +732,9 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
             }
         }
     }
+#ifdef VP_STAMP
+    st4 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (OUT == 0) {
         acc = wave_sum(acc);
         double* red = fl + I.span;
@@ -750,6 +766,12 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
                 __hip_atomic_store(F.ticket + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+#ifdef VP_STAMP
+            if (F.stamps) {     // diagnostic only: wall-clock stamps (100 MHz) of this workgroup's phases
+                unsigned long long* sp = F.stamps + ((size_t)t * gridDim.x + w) * 8;
+                sp[0] = st0; sp[1] = st1; sp[2] = st2; sp[3] = st3; sp[4] = st4; sp[5] = __builtin_amdgcn_s_memrealtime();
+            }
+#endif
         }
     }
 }
