@@ -85,13 +85,15 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 exercises the RCCL path (init + all_gather) even with a single rank
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from rbvfit_amd.workloads import make_workload
 
@@ -101,27 +103,27 @@ def main():
     W, D = wl.thetas.shape
     d_theta = torch.from_numpy(wl.thetas).cuda()
     d_out = torch.empty(W, dtype=torch.float64, device="cuda")
-    gathered = torch.empty(W * world, dtype=torch.float64, device="cuda") if world > 1 else None
+    gathered = torch.empty(W * world, dtype=torch.float64, device="cuda") if use_dist else None
     stream = torch.cuda.current_stream()
 
     def step():
         eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, d_out)
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -186,7 +188,9 @@ def main():
             line["cpu_baseline"] = cb
             line["parity_vs_cpu_baseline_max_rel"] = float(np.max(np.abs(result[:n] / cpu_vals[:n] - 1)))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
+        if rank == 0 and gathered is not None:
+            assert torch.equal(gathered[:W], d_out), "all-gathered lnprob differs from the local block"
         dist.destroy_process_group()
 
 
