@@ -261,3 +261,33 @@ def test_curve_of_growth_grid_is_one_batch():
             fl = vo.model_flux(d, np.array([Nlist[i], blist[j], 0.0]), cog.wave)
             assert abs(cog.Wlist[i, j] - trap(1 - fl, x=cog.wave)) < 1e-11
     assert np.all(np.diff(cog.Wlist, axis=0) > 0)            # EW grows with N
+
+
+@pytest.mark.parametrize("K", [65, 301, 1025, 2049])
+def test_long_tabulated_kernels(K):
+    """Long LSFs take wider tiles (2/4-wave workgroups, up to 8192 evaluated pixels per tile)."""
+    import rbvfit_amd
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    rng = np.random.default_rng(K)
+    cfg = FitConfiguration(); cfg.add_system(0.348, "MgII", [2796.35, 2803.53], 2)
+    j = np.arange(K) - K // 2
+    taps = np.exp(-0.5 * (j / (K / 9.0)) ** 2) * (1 + 0.3 * np.sin(j / 7.0) ** 2) + 1e-4
+    model = VoigtModel(cfg, FWHM="6.5", kernel_taps=taps)
+    data = model.compile().data
+    wave = np.linspace(3755.0, 3795.0, 5000)
+    th = np.array([[13.5, 13.2, 15.0, 25.0, -40.0, 20.0], [14.1, 12.9, 8.0, 31.0, -55.0, 12.0]])
+    od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors, data.N_indices,
+                            data.b_indices, data.v_indices, data.taps, data.lsf_mode, data.voigt_method)
+    err = np.full(wave.size, 0.05)
+    flux = vo.model_flux(od, th[0], wave) + rng.normal(0, 0.05, wave.size)
+    inst = vo.OracleInstrument.from_error(od, wave, flux, err)
+    lb, ub = th.min(0) - 5, th.max(0) + 5
+    with rbvfit_amd.Engine(0) as e:
+        e.set_bounds(lb, ub)
+        e.add_instrument(wave, flux, inst.inv_sigma2, inst.log_inv_sigma2, **data.engine_kwargs())
+        got = e.lnprob(th)
+        fl = e.model_flux(0, th)
+    np.testing.assert_allclose(got, vo.lnprob_batch(th, lb, ub, [inst]), rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    for i in range(2):
+        np.testing.assert_allclose(fl[i], vo.model_flux(od, th[i], wave), rtol=0, atol=FLUX_ATOL)
