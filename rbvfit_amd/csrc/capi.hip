@@ -457,9 +457,17 @@ int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
     if ((rc = ensure_pinned(c, tb + ob))) return rc;
     std::memcpy(c->h_pinned, theta, tb);
     double* h_out = c->h_pinned + (size_t)W * D;
-    HIP_TRY(c, hipMemcpyAsync(c->d_theta, c->h_pinned, tb, hipMemcpyHostToDevice, c->stream));
-    if ((rc = enqueue_lnprob(c, W, c->d_theta, c->d_out, c->stream))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
+    if (tb <= (size_t)16 * 1024 && !getenv("RBVFIT_AMD_NO_ZEROCOPY")) {
+        // small batch: the kernels read theta from / write lnprob to the pinned (host-coherent) buffer
+        // directly over PCIe -- no H2D/D2H copy commands on the latency path
+        double* dp = nullptr;
+        HIP_TRY(c, hipHostGetDevicePointer((void**)&dp, c->h_pinned, 0));
+        if ((rc = enqueue_lnprob(c, W, dp, dp + (size_t)W * D, c->stream))) return rc;
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(c->d_theta, c->h_pinned, tb, hipMemcpyHostToDevice, c->stream));
+        if ((rc = enqueue_lnprob(c, W, c->d_theta, c->d_out, c->stream))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::memcpy(out, h_out, ob);
     return VP_OK;
