@@ -83,3 +83,38 @@ def test_random_configuration(seed):
         np.testing.assert_allclose(fl[i], vo.model_flux(od, thetas[i], wave), rtol=0, atol=FLUX_ATOL)
     for i in range(2):
         np.testing.assert_allclose(un[i], vo.model_flux(od, thetas[i], wave, return_unconvolved=True), rtol=0, atol=FLUX_ATOL)
+
+
+def test_more_than_64_and_128_lines():
+    """Line-core flags are kept in 64-line mask words: exercise 2 and 3 words, with clusters that
+    straddle the word boundaries."""
+    import rbvfit_amd
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    rng = np.random.default_rng(99)
+    for n_sys, comps in ((2, 9), (3, 11)):            # 2*4*9 = 72 lines, 3*4*11 = 132 lines
+        cfg = FitConfiguration()
+        for s in range(n_sys):
+            cfg.add_system(0.30 + 0.004 * s, "FeII", [2600.1729, 2586.650, 2382.765, 2344.214], comps)
+        model = VoigtModel(cfg, FWHM="4.0")
+        data = model.compile().data
+        assert data.n_lines == n_sys * 4 * comps
+        C = cfg.total_components
+        wave = np.linspace(3030.0, 3420.0, 7000)
+        theta = np.concatenate([rng.uniform(12.5, 14.5, C), rng.uniform(5, 40, C), rng.uniform(-200, 200, C)])
+        lb = np.concatenate([np.full(C, 10.0), np.full(C, 1.0), np.full(C, -400.0)])
+        ub = np.concatenate([np.full(C, 18.0), np.full(C, 150.0), np.full(C, 400.0)])
+        thetas = np.clip(theta + 0.05 * rng.standard_normal((4, 3 * C)), lb + 1e-9, ub - 1e-9)
+        od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors, data.N_indices,
+                                data.b_indices, data.v_indices, data.taps, data.lsf_mode, data.voigt_method)
+        err = np.full(wave.size, 0.05)
+        flux = vo.model_flux(od, thetas[0], wave) + rng.normal(0, 0.05, wave.size)
+        inst = vo.OracleInstrument.from_error(od, wave, flux, err)
+        with rbvfit_amd.Engine(0) as e:
+            e.set_bounds(lb, ub)
+            e.add_instrument(wave, flux, inst.inv_sigma2, inst.log_inv_sigma2, **data.engine_kwargs())
+            got = e.lnprob(thetas)
+            fl = e.model_flux(0, thetas[:2])
+        np.testing.assert_allclose(got, vo.lnprob_batch(thetas, lb, ub, [inst]), rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        for i in range(2):
+            np.testing.assert_allclose(fl[i], vo.model_flux(od, thetas[i], wave), rtol=0, atol=FLUX_ATOL)
