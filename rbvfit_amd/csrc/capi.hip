@@ -394,12 +394,12 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method; d.line_sel = -1;
     d.NCm = NCm; d.cl_mp = d_clmp; d.cl_end = d_clend;
 #undef UP
-    // Tile geometry: one wave evaluates 256 consecutive pixels (4 chunks of 64, register-blocked);
+    // Tile geometry: one wave evaluates 2*RB chunks of 64 consecutive pixels (RB register-blocked per pass);
     // a workgroup is 1, 2 or 4 such waves.  Single-wave workgroups need no cross-wave barrier and
     // let the hardware balance the walkers' tiles; longer LSFs take wider tiles to keep the halo
     // (K-1 re-evaluated pixels per tile) a small fraction.
     int nwaves = Kuse <= 33 ? 1 : Kuse <= 65 ? 2 : 4;
-    int span = 256 * nwaves;
+    int span = 2 * 64 * vp::RB * nwaves;                 // two register-blocked passes per wave
     if (const char* sp = getenv("RBVFIT_AMD_SPAN")) span = atoi(sp);     // tuning experiments (multiple of 64)
     if (const char* nw = getenv("RBVFIT_AMD_WAVES")) nwaves = atoi(nw);
     if (Kuse > 257) { span = std::min(8192, ((4 * Kuse + 63) / 64) * 64); nwaves = 4; }

@@ -376,7 +376,7 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __re
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span = 256 pixels per wave)
 #ifndef VP_RB
-#define VP_RB 2
+#define VP_RB 3     // measured: RB=3 (91 VGPRs, 5 waves/SIMD) beats RB=2 (79, 6) and RB=4 (109, 4) by 3-5 %
 #endif
 constexpr int RB = VP_RB;         // 64-pixel chunks per wave pass (register blocking / ILP)
 
