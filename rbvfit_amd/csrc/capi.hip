@@ -217,7 +217,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
         if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-        hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * (in.dev.L + in.dev.NCm)), dim3(64), 0, s, d_theta, W, c->D, in.lines,
+        hipLaunchKernelGGL(vp::prep_lines_kernel, dim3((W * (in.dev.L + in.dev.NCm) + vp::PREP_WAVES - 1) / vp::PREP_WAVES), dim3(64 * vp::PREP_WAVES), 0, s, d_theta, W, c->D, in.lines,
                            c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr);
         size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin,
@@ -486,7 +486,7 @@ int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* 
     const Instrument& in = c->inst[inst];
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;      // model_flux has no prior box: theta may be anything
     if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * (in.dev.L + in.dev.NCm)), dim3(64), 0, s, d_theta, W, c->D, in.lines, c->d_lb,
+    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3((W * (in.dev.L + in.dev.NCm) + vp::PREP_WAVES - 1) / vp::PREP_WAVES), dim3(64 * vp::PREP_WAVES), 0, s, d_theta, W, c->D, in.lines, c->d_lb,
                        c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr, gen ? c->d_genflag : (int*)nullptr);
     const vp::FinalizeArgs nofin{};
     const int* gf = gen ? c->d_genflag : (const int*)nullptr;
@@ -538,7 +538,7 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;
     if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(W * (in.dev.L + in.dev.NCm)), dim3(64), 0, s, c->d_theta, W, c->D, in.lines, c->d_lb,
+    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3((W * (in.dev.L + in.dev.NCm) + vp::PREP_WAVES - 1) / vp::PREP_WAVES), dim3(64 * vp::PREP_WAVES), 0, s, c->d_theta, W, c->D, in.lines, c->d_lb,
                        c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr, gen ? c->d_genflag : (int*)nullptr);
     const vp::FinalizeArgs nofin{};
     const int* gf = gen ? c->d_genflag : (const int*)nullptr;

@@ -234,15 +234,18 @@ __device__ __forceinline__ void prep_cluster(const double* __restrict__ th, cons
 // One 64-thread workgroup per (walker, line).  Follows _evaluate_compiled_model's scalar prologue
 // (voigt_model.py:192-200) and _vectorized_voigt_tau's per-line constants (:142-149) operation by
 // operation (the file is compiled with -ffp-contract=off, so nothing here is fused).
-__global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict__ theta, int W, int D,
+constexpr int PREP_WAVES = 4;        // records per workgroup (one per wave)
+__global__ __launch_bounds__(64 * PREP_WAVES) void prep_lines_kernel(const double* __restrict__ theta, int W, int D,
                                                         LinesDev T, const double* __restrict__ lb,
                                                         const double* __restrict__ ub,
                                                         double* __restrict__ lc, int* __restrict__ flags,
                                                         int do_flags, double* __restrict__ lnprob_out,
                                                         int* __restrict__ genflag) {
     const int nrec = T.L + T.NCm;                     // records per walker: lines, then clusters
-    const int w = blockIdx.x / nrec, l = blockIdx.x % nrec;
-    const int lane = threadIdx.x;
+    const int ridx = blockIdx.x * PREP_WAVES + (threadIdx.x >> 6);
+    if (ridx >= W * nrec) return;                     // whole wave
+    const int w = ridx / nrec, l = ridx % nrec;
+    const int lane = threadIdx.x & 63;
     const double* th = theta + (size_t)w * D;
     if (l >= T.L) {                                   // ---- multipole record of one cluster ----
         prep_cluster(th, T, l - T.L, lc + ((size_t)w * nrec + l) * LC_STRIDE, lane);
@@ -259,9 +262,20 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
     }
     double* rec = lc + ((size_t)w * nrec + l) * LC_STRIDE;
     const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
-    const double N = exp10(th[T.N_idx[l]]);            // :192  (10**theta; <= 1 ulp, only scales tau)
-    const double b = th[T.b_idx[l]];                   // :193
-    const double v = th[T.v_idx[l]];                   // :194
+    // theta row and index tables are fetched concurrently (one memory round trip): lane d holds
+    // theta[d], the three entries are then picked out with a wave shuffle (D <= 64), else by index
+    double thN, thb, thv;
+    if (D <= 64) {
+        const double trow = th[min(lane, D - 1)];
+        thN = __shfl(trow, T.N_idx[l], 64);
+        thb = __shfl(trow, T.b_idx[l], 64);
+        thv = __shfl(trow, T.v_idx[l], 64);
+    } else {
+        thN = th[T.N_idx[l]]; thb = th[T.b_idx[l]]; thv = th[T.v_idx[l]];
+    }
+    const double N = exp10(thN);                       // :192  (10**theta; <= 1 ulp, only scales tau)
+    const double b = thb;                              // :193
+    const double v = thv;                              // :194
     // quantities that enter x are formed with the reference's operations and roundings ...
     const double z_total = zf * (1.0 + v / C_KMS) - 1.0;   // :200
     const double d = 1.0 + z_total;                    // :204
