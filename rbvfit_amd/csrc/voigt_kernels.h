@@ -15,7 +15,7 @@
 //              chi^2 term vs flux / inv_sigma2, wave reduce -> partial[w][tile] (vfit_mcmc.py:309-311)
 //              last-arriving tile of a walker (agent-scope atomics) sums the partials in fixed order
 //              and writes lnprob = -0.5 (sum - sum log w)                      (vfit_mcmc.py:348-353)
-//   Two instances: GENERIC=false (no out-of-line generic Faddeeva, 79 VGPRs, 6 waves/SIMD) and
+//   Two instances: GENERIC=false (no out-of-line generic Faddeeva, 91 VGPRs, 5 waves/SIMD) and
 //   GENERIC=true (handles walkers flagged by prep; launched only when the prior box allows a > 0.1).
 //
 // HBM layout: spectra (wave, 1/wave, flux, inv_sigma2) are 4 dense fp64 arrays per instrument,
