@@ -11,6 +11,11 @@ full ensemble and proposes identical moves; only the likelihood evaluation is sp
 
     post = ShardedPosterior(local_eval)         # local_eval(theta_block (w,D)) -> (w,) lnprob
     lnp = post(theta_all)                        # (W,) on every rank
+
+Island usage (``IslandEnsemble`` / ``PipelinedGather``): every rank owns its block of walkers
+outright -- proposals, lnprob and accept/reject need local data only -- so the all-gather of step
+k's lnprob (for chain storage and convergence monitoring) is issued asynchronously on RCCL's stream
+and overlaps step k+1's kernels; nothing on a rank's critical path waits for a peer.
 """
 from __future__ import annotations
 
@@ -87,3 +92,123 @@ class DeviceShardedPosterior:
         if self.world > 1:
             self._dist.all_gather_into_tensor(self.gathered, self.out, group=self.group)
         return self.gathered
+
+
+class PipelinedGather:
+    """Chunked, double-buffered, asynchronous all-gather of a rank-local device vector.
+
+    ``launch(out)`` enqueues the local evaluation that fills ``out`` (a (W,) float64 tensor) on
+    the current stream -- e.g. ``Engine.lnprob_device``.  ``step()`` runs it into row k % every of
+    the current chunk buffer; when a chunk of ``every`` steps is full, ONE
+    ``all_gather_into_tensor(..., async_op=True)`` ships the whole (every, W) block: with RCCL the
+    collective runs on the process group's own stream behind an event, so it overlaps the next
+    chunk's kernels, and both the per-collective host cost and the latency-bound wire time are
+    paid once per ``every`` steps (a few larger collectives instead of many tiny ones).  A chunk
+    buffer is reused only after its collective has been waited for (a stream-side wait, not a
+    host block).  ``flush()`` ships a partial chunk and waits for everything in flight;
+    ``chunk(age)`` is the (world, every, W) result of the ``age``-th most recent SHIPPED chunk."""
+
+    def __init__(self, launch: Callable, W: int, device=None, group=None, every: int = 32, depth: int = 2):
+        import torch
+        import torch.distributed as dist
+        if every < 1 or depth < 2:
+            raise ValueError("every >= 1 and depth >= 2 required")
+        self._dist, self.group, self.launch = dist, group, launch
+        self.W, self.every, self.depth = int(W), int(every), int(depth)
+        self.on = dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.out = [torch.empty(self.every, self.W, dtype=torch.float64, device=device) for _ in range(depth)]
+        self.full = ([torch.empty(self.world, self.every, self.W, dtype=torch.float64, device=device)
+                      for _ in range(depth)] if self.on else [o.view(1, self.every, self.W) for o in self.out])
+        self.work = [None] * depth
+        self.rows = [0] * depth          # valid rows in each shipped chunk
+        self.k = 0                       # steps taken
+        self.shipped = 0                 # chunks shipped
+
+    def _wait(self, i):
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+
+    def _ship(self, i, rows):
+        self.rows[i] = rows
+        if self.on:
+            self.work[i] = self._dist.all_gather_into_tensor(self.full[i].view(-1), self.out[i].view(-1),
+                                                             group=self.group, async_op=True)
+        self.shipped += 1
+
+    def step(self):
+        c, j = divmod(self.k, self.every)
+        i = c % self.depth
+        if j == 0:
+            self._wait(i)                # the collective that last read this buffer
+        row = self.out[i][j]
+        self.launch(row)
+        self.k += 1
+        if j == self.every - 1:
+            self._ship(i, self.every)
+        return row
+
+    def flush(self):
+        c, j = divmod(self.k, self.every)
+        if j:                            # partial chunk: ship it (rows >= j are stale) and start a new one
+            self._ship(c % self.depth, j)
+            self.k = (c + 1) * self.every
+        for i in range(self.depth):
+            self._wait(i)
+
+    def chunk(self, age: int = 0):
+        """(world, rows, W) view of a shipped chunk; age 0 = the most recent one."""
+        if not 0 <= age < min(self.depth, self.shipped):
+            raise ValueError("no such chunk in flight (never shipped, or its buffer has been reused)")
+        if age == self.depth - 1 and self.k % self.every:
+            raise ValueError("that chunk's buffer is being refilled")
+        i = (self.shipped - 1 - age) % self.depth
+        self._wait(i)
+        return self.full[i][:, : self.rows[i]]
+
+
+class IslandEnsemble:
+    """G independent stretch-move ensembles, one per rank, targeting the same posterior.
+
+    Each rank runs ``StretchMoveSampler`` over its own ``nwalkers_local`` walkers (seed offset by the
+    rank) against its own engine, so an MCMC step needs no exchange at all; ``gather_chain`` then
+    collects the per-rank chains with ONE all-gather (one large collective instead of one per
+    step).  Statistically this is the usual "many short independent ensembles" scheme: the pooled
+    samples are draws from the same posterior, and between-island agreement is a convergence check
+    (``island_means``)."""
+
+    def __init__(self, local_lnprob: Callable, nwalkers_local: int, ndim: int, seed: int = 0, group=None,
+                 device: Optional[str] = None):
+        import torch.distributed as dist
+        from .sampler import StretchMoveSampler
+        self._dist, self.group, self.device = dist, group, device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.sampler = StretchMoveSampler(nwalkers_local, ndim, local_lnprob, seed=seed * 1000003 + self.rank)
+
+    def run_mcmc(self, p0_local, nsteps: int):
+        return self.sampler.run_mcmc(p0_local, nsteps)
+
+    def gather_chain(self, discard: int = 0):
+        """(nsteps-discard, nwalkers_local*world, D) chain and matching lnprob on every rank."""
+        import torch
+        c = np.ascontiguousarray(self.sampler.chain[discard:])
+        lp = np.ascontiguousarray(self.sampler.lnprobability[discard:])
+        if self.world == 1:
+            return c, lp
+        packed = torch.from_numpy(np.concatenate([c.reshape(-1), lp.reshape(-1)]))
+        if self.device:
+            packed = packed.to(self.device)
+        full = torch.empty(packed.numel() * self.world, dtype=torch.float64, device=packed.device)
+        self._dist.all_gather_into_tensor(full, packed, group=self.group)
+        full = full.cpu().numpy().reshape(self.world, -1)
+        cs = [full[r, : c.size].reshape(c.shape) for r in range(self.world)]
+        lps = [full[r, c.size:].reshape(lp.shape) for r in range(self.world)]
+        return np.concatenate(cs, axis=1), np.concatenate(lps, axis=1)
+
+    def island_means(self, discard: int = 0):
+        """(world, D) posterior means per island -- they must agree within the sampling error."""
+        c, _ = self.gather_chain(discard)
+        n = self.sampler.nwalkers
+        return np.stack([c[:, r * n:(r + 1) * n].reshape(-1, c.shape[-1]).mean(axis=0) for r in range(self.world)])

@@ -69,6 +69,23 @@ class Workload:
         """read wave, flux, inv_sigma2 once per walker-eval, theta, write lnprob."""
         return sum(24 * p for p in self.pixels) + 8 * self.ndim + 8
 
+    @property
+    def algorithmic_flops_per_eval(self) -> float:
+        """SURVEY 8(d) secondary roof: per (line, pixel) 8 (x) + H (12 wing / 150 core) + 1, per
+        pixel 30 (exp) + 2K + 4; "core" = |x| < 8 Doppler widths at theta_true."""
+        total = 0.0
+        for data, (wave, _, _) in zip(self.tables, self.spectra):
+            th = self.theta_true
+            b = th[np.asarray(data.b_indices)]
+            v = th[np.asarray(data.v_indices)]
+            lam_obs = np.asarray(data.atomic_lambda0) * np.asarray(data.z_factors) * (1.0 + v / 299792.458)
+            x = 299792.458 * (lam_obs[:, None] / wave[None, :] - 1.0) / b[:, None]
+            ncore = int(np.count_nonzero(np.abs(x) < 8.0))
+            L, P = x.shape
+            K = 0 if data.taps is None else len(data.taps)
+            total += 9.0 * L * P + 150.0 * ncore + 12.0 * (L * P - ncore) + P * (30.0 + 2.0 * K + 4.0)
+        return total
+
 
 def make_workload(name: str, walkers: Optional[int] = None, device_id: int = 0, pixels: Optional[int] = None,
                   walker_seed: int = 1) -> Workload:

@@ -9,7 +9,7 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 wl = make_workload("C1", walkers=W)
 eng = wl.engine
 lib = eng._lib
-ntiles = 18
+ntiles = int(os.environ.get("NTILES", "12"))
 n = W * ntiles
 for _ in range(3):
     eng.lnprob(wl.thetas)
