@@ -207,6 +207,22 @@ size_t prof_mark(vp_ctx* c, hipStream_t s) {
 // enqueue the whole lnprob pipeline for device-resident theta / out: per instrument a prep launch
 // (line records; the first one also applies the box prior and writes -inf rows) and a tile launch;
 // the last-arriving tile workgroup of each walker performs the final reduction.
+// Record preparation launch: one lane per record, 64 records per wave (fewer per wave measured no
+// faster even at 512 walkers x 4 lines; RBVFIT_AMD_PREP_RPW overrides for experiments).
+static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_theta, int W, int do_flags, double* d_out,
+                        int* genflag, hipStream_t s) {
+    const long nline = (long)W * in.dev.L, ncl = (long)W * in.dev.NCm;
+    int rpw = 64;
+    if (const char* e = getenv("RBVFIT_AMD_PREP_RPW")) rpw = std::max(1, std::min(64, atoi(e)));
+    vp::PrepGrid g;
+    g.rpw = rpw;
+    g.nb_line = (int)((nline + rpw - 1) / rpw);
+    g.nb_cl = (int)((ncl + rpw - 1) / rpw);
+    g.nb_flag = do_flags ? (W + 63) / 64 : 0;
+    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(g.nb_line + g.nb_cl + g.nb_flag), dim3(64), 0, s, d_theta, W, c->D,
+                       in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g);
+}
+
 int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
     int tile_off = 0;
     const bool prof = c->profiling;
@@ -217,8 +233,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
         if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-        hipLaunchKernelGGL(vp::prep_lines_kernel, dim3((W * (in.dev.L + in.dev.NCm) + vp::PREP_WAVES - 1) / vp::PREP_WAVES), dim3(64 * vp::PREP_WAVES), 0, s, d_theta, W, c->D, in.lines,
-                           c->d_lb, c->d_ub, c->d_lc, c->d_flags, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr);
+        launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr, s);
         size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin,
                               gen ? c->d_genflag : (const int*)nullptr);
@@ -486,8 +501,7 @@ int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* 
     const Instrument& in = c->inst[inst];
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;      // model_flux has no prior box: theta may be anything
     if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3((W * (in.dev.L + in.dev.NCm) + vp::PREP_WAVES - 1) / vp::PREP_WAVES), dim3(64 * vp::PREP_WAVES), 0, s, d_theta, W, c->D, in.lines, c->d_lb,
-                       c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr, gen ? c->d_genflag : (int*)nullptr);
+    launch_prep(c, in, d_theta, W, 0, nullptr, gen ? c->d_genflag : (int*)nullptr, s);
     const vp::FinalizeArgs nofin{};
     const int* gf = gen ? c->d_genflag : (const int*)nullptr;
     if (convolved) {
@@ -538,8 +552,7 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;
     if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-    hipLaunchKernelGGL(vp::prep_lines_kernel, dim3((W * (in.dev.L + in.dev.NCm) + vp::PREP_WAVES - 1) / vp::PREP_WAVES), dim3(64 * vp::PREP_WAVES), 0, s, c->d_theta, W, c->D, in.lines, c->d_lb,
-                       c->d_ub, c->d_lc, c->d_flags, 0, (double*)nullptr, gen ? c->d_genflag : (int*)nullptr);
+    launch_prep(c, in, c->d_theta, W, 0, nullptr, gen ? c->d_genflag : (int*)nullptr, s);
     const vp::FinalizeArgs nofin{};
     const int* gf = gen ? c->d_genflag : (const int*)nullptr;
     for (size_t l = 0; l < L; ++l) {
@@ -569,7 +582,7 @@ int vp_voigt_h(vp_ctx* c, int na, const double* a, int nx, const double* x, doub
     double* d_o = d_x + nx;
     HIP_TRY(c, hipMemcpyAsync(d_a, a, na * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_x, x, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(vp::prep_h_kernel, dim3(na), dim3(64), 0, c->stream, d_a, d_rec);
+    hipLaunchKernelGGL(vp::prep_h_kernel, dim3((na + 63) / 64), dim3(64), 0, c->stream, d_a, (int)na, d_rec);
     hipLaunchKernelGGL(vp::voigt_h_kernel, dim3((nx + 255) / 256, na), dim3(256), 0, c->stream, d_rec, d_x, nx, d_o);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, d_o, (size_t)na * nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -2,7 +2,7 @@
 //
 // Data flow of one lnprob batch (W walkers; instruments are launched back to back on one stream):
 //
-//   prep_lines_kernel   grid W*L x 64 thr   theta row -> per-(walker,line) 512-B record (vp::LC_*),
+//   prep_lines_kernel   one LANE per record   theta row -> per-(walker,line) 512-B record (vp::LC_*),
 //                                           box-prior flag per walker + -inf rows (vfit_mcmc.py:291-295),
 //                                           optional flag for walkers with lines outside the fast domain
 //   tile_kernel         grid (W, tiles) x 64/128/256 thr   workgroup = walker x pixel tile
@@ -107,9 +107,9 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// Fill one record from (T, a) and, when given, the x-mapping scalars.  Called by all 64 lanes of a
-// wave; lane-parallel over table entries.
-__device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, double T, double a) {
+// Fill one record from (T, a).  ONE LANE PER RECORD: a wave prepares up to 64 records at once, so
+// the scalar prologue of a record is executed once instead of once per lane.
+__device__ __forceinline__ void fill_record(double* __restrict__ rec, double T, double a) {
     int mode = 0;
     if (!(a >= 0.0) || !(a < 7.0)) mode = 2;         // a < 0, a >= 7
     else if (a > 0.1) mode = 1;
@@ -118,31 +118,57 @@ __device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, 
     const double a2 = a * a;
     // Gaussian-sum table and its plain sum: only lines outside the fast domain need them
     double S1 = 0.0;
-    if (mode == 1) {                                  // wave-uniform
-        double tb = 0.0;
-        if (lane < NCORE) {
-            const double hn = ALG916_H * (double)(lane + 1);
+    if (mode == 1) {
+        for (int n = 0; n < NCORE; ++n) {
+            const double hn = ALG916_H * (double)(n + 1);
             const double hn2 = hn * hn;
-            tb = exp(-hn2) / (hn2 + a2);
+            const double tb = exp(-hn2) / (hn2 + a2);
+            S1 += tb;
+            rec[LC_TBL0 + n] = (0.5 * ALG916_C * a) * tb;
         }
-        S1 = wave_sum(tb);
-        if (lane < NCORE) rec[LC_TBL0 + lane] = (0.5 * ALG916_C * a) * tb;
     }
     // wing coefficients
-    if (lane < NWING) {
+    const double pref = T * (a * INV_SQRT_PI);
+#pragma unroll
+    for (int m = 0; m < NWING; ++m) {
         double cm = 0.0;
-        for (int i = lane; i >= 0; --i) cm = __builtin_fma(cm, a2, g_wing.c[lane][i]);
-        rec[LC_K0 + lane] = (T * (a * INV_SQRT_PI)) * cm;
+#pragma unroll
+        for (int i = m; i >= 0; --i) cm = __builtin_fma(cm, a2, g_wing.c[m][i]);
+        rec[LC_K0 + m] = pref * cm;
     }
-    if (lane == 0) {
-        rec[LC_T] = T;
-        rec[LC_Y] = a;
-        rec[LC_ACOS] = (mode == 1) ? erfcx(a) - (ALG916_C * a) * S1 : 0.0;
-        reinterpret_cast<int*>(rec + LC_MODE)[0] = mode;
-        reinterpret_cast<int*>(rec + LC_MODE)[1] = core_terms(a);
-        // exp(a^2): five Taylor terms in the fast domain (a <= 0.1, remainder 1e-22)
-        rec[LC_EA2] = (mode == 0) ? 1.0 + a2 * (1.0 + a2 * (0.5 + a2 * (1.0 / 6 + a2 * (1.0 / 24)))) : exp(a2);
-    }
+    rec[LC_T] = T;
+    rec[LC_Y] = a;
+    rec[LC_ACOS] = (mode == 1) ? erfcx(a) - (ALG916_C * a) * S1 : 0.0;
+    reinterpret_cast<int*>(rec + LC_MODE)[0] = mode;
+    reinterpret_cast<int*>(rec + LC_MODE)[1] = core_terms(a);
+    // exp(a^2): five Taylor terms in the fast domain (a <= 0.1, remainder 1e-22)
+    rec[LC_EA2] = (mode == 0) ? 1.0 + a2 * (1.0 + a2 * (0.5 + a2 * (1.0 / 6 + a2 * (1.0 / 24)))) : exp(a2);
+}
+
+// Per-line scalars of one (walker, line): follows _evaluate_compiled_model's scalar prologue
+// (voigt_model.py:192-200) and _vectorized_voigt_tau's per-line constants (:142-149) operation by
+// operation (the file is compiled with -ffp-contract=off, so nothing here is fused).
+struct LineScalars { double d, freq0, ibf, a, Tl, cfd, Ax, Bx; };
+__device__ __forceinline__ LineScalars line_scalars(const double* __restrict__ th, const LinesDev& T, int l) {
+    LineScalars s;
+    const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
+    const double N = exp10(th[T.N_idx[l]]);            // :192  (10**theta; <= 1 ulp, only scales tau)
+    const double b = th[T.b_idx[l]];                   // :193
+    const double v = th[T.v_idx[l]];                   // :194
+    // quantities that enter x are formed with the reference's operations and roundings ...
+    const double z_total = zf * (1.0 + v / C_KMS) - 1.0;   // :200
+    s.d = 1.0 + z_total;                               // :204
+    const double b_f = b / lam0 * 1e13;                // :142
+    s.freq0 = T.freq0[l];                              // :143  C_FREQ / lambda0, IEEE quotient from the host
+    // ... the others only need ~1e-16 relative accuracy (reciprocal + Newton instead of IEEE division)
+    s.ibf = fast_rcp(b_f);
+    const double constant = ATOMIC_CONSTANT * fast_rcp(s.freq0 * b);   // :146
+    s.a = gam * (s.ibf * 0.079577471545947667884);     // :149  gamma / (4 pi b_f)
+    s.Tl = (N * fo) * constant;                        // :158
+    s.cfd = C_FREQ * s.d;
+    s.Ax = s.cfd * s.ibf;
+    s.Bx = s.freq0 * s.ibf;
+    return s;
 }
 
 // Multipole expansion of one cluster (the components of one transition) about its centre, for the
@@ -152,164 +178,128 @@ __device__ __forceinline__ void fill_record(double* __restrict__ rec, int lane, 
 // A_c is the smallest A_l of the cluster (alpha_l >= 1), B_c centres the delta_l.  The record is used
 // only where every |y| >= Yfar = max(100 + max|delta|, 10 max|delta|): there each member is in its
 // 4-term asymptotic regime (|x_l| >= 100) and the expansion ratio is <= 0.1 (truncation < 2e-12 of
-// an already tiny far-wing tau).  Lane l' handles member l'; 64-thread wave.
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
-}
+// an already tiny far-wing tau).  One lane per cluster record; two passes over the members.
 __device__ __forceinline__ void prep_cluster(const double* __restrict__ th, const LinesDev& T, int k,
-                                             double* __restrict__ rec, int lane) {
+                                             double* __restrict__ rec) {
     const int first = T.cl_first[k], n = T.cl_count[k];
-    const bool mem = lane < n;
-    const int l = first + (mem ? lane : 0);
-    const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
-    const double N = exp10(th[T.N_idx[l]]);
-    const double b = th[T.b_idx[l]], v = th[T.v_idx[l]];
-    const double d = 1.0 + (zf * (1.0 + v / C_KMS) - 1.0);
-    const double b_f = b / lam0 * 1e13;
-    const double freq0 = T.freq0[l];
-    const double ibf = fast_rcp(b_f);
-    const double a = gam * (ibf * 0.079577471545947667884);
-    const double Tl = (N * fo) * (ATOMIC_CONSTANT * fast_rcp(freq0 * b));
-    const double A = (C_FREQ * d) * ibf, B = freq0 * ibf;
-    const bool ok = (a >= 0.0) && (a <= 0.1) && (fabs(Tl) <= 1.79e308) && (fabs(A) <= 1.79e308) && (fabs(B) <= 1.79e308)
-                    && (A > 0.0);
-    const int allok = __all(ok || !mem);
-    const double Ac = wave_min(mem ? A : 1.79e308);
-    const double g0 = B * fast_rcp(A);                         // line centre in 1/wave units
-    const double g0c = wave_sum(mem ? g0 : 0.0) / (double)n;
+    bool allok = true;
+    double Ac = 1.79e308, g0sum = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const LineScalars s = line_scalars(th, T, first + j);
+        allok = allok && (s.a >= 0.0) && (s.a <= 0.1) && (fabs(s.Tl) <= 1.79e308) && (fabs(s.Ax) <= 1.79e308)
+                && (fabs(s.Bx) <= 1.79e308) && (s.Ax > 0.0);
+        Ac = fmin(Ac, s.Ax);
+        g0sum += s.Bx * fast_rcp(s.Ax);                         // line centre in 1/wave units
+    }
+    const double g0c = g0sum / (double)n;
     const double Bc = Ac * g0c;
-    const double alpha = A * fast_rcp(Ac);                      // >= 1
-    const double delta = Ac * (g0c - g0);                       // x_l = alpha (y + delta)
-    const double dmax = wave_max(mem ? fabs(delta) : 0.0);
-    // member's wing coefficients K_m, m < 4, divided by alpha^(2m+2)
-    double Km[MP_MWING];
-    {
-        const double a2 = a * a, pref = Tl * (a * INV_SQRT_PI);
+    double dmax = 0.0;
+    double Q[MP_NQ];
+#pragma unroll
+    for (int jq = 0; jq < MP_NQ; ++jq) Q[jq] = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const LineScalars s = line_scalars(th, T, first + j);
+        const double g0 = s.Bx * fast_rcp(s.Ax);
+        const double alpha = s.Ax * fast_rcp(Ac);                // >= 1
+        const double delta = Ac * (g0c - g0);                    // x_l = alpha (y + delta)
+        dmax = fmax(dmax, fabs(delta));
+        // member's wing coefficients K_m, m < 4, divided by alpha^(2m+2)
+        double Km[MP_MWING];
+        const double a2 = s.a * s.a, pref = s.Tl * (s.a * INV_SQRT_PI);
         const double ia2 = fast_rcp(alpha * alpha);
         double ipow = ia2;
 #pragma unroll
         for (int m = 0; m < MP_MWING; ++m) {
             double cm = 0.0;
+#pragma unroll
             for (int i = m; i >= 0; --i) cm = __builtin_fma(cm, a2, g_wing.c[m][i]);
-            Km[m] = mem ? pref * cm * ipow : 0.0;
+            Km[m] = pref * cm * ipow;
             ipow *= ia2;
         }
-    }
-    // Q_j, j = 2..14
-    double dpow[MP_NQ + 1];                                     // (-delta)^k, k = 0..13
-    dpow[0] = 1.0;
+        double dpow[MP_NQ + 1];                                  // (-delta)^k, k = 0..13
+        dpow[0] = 1.0;
 #pragma unroll
-    for (int kk = 1; kk <= MP_NQ; ++kk) dpow[kk] = dpow[kk - 1] * (-delta);
+        for (int kk = 1; kk <= MP_NQ; ++kk) dpow[kk] = dpow[kk - 1] * (-delta);
 #pragma unroll
-    for (int jq = 0; jq < MP_NQ; ++jq) {
-        const int j = jq + MP_JMIN;
-        double q = 0.0;
+        for (int jq = 0; jq < MP_NQ; ++jq) {
+            const int jj = jq + MP_JMIN;
 #pragma unroll
-        for (int m = 0; m < MP_MWING; ++m) {
-            const int nn = 2 * m + 2;
-            if (nn <= j) {
-                // C(j-1, nn-1)
-                double binom = 1.0;
-                for (int t = 1; t <= nn - 1; ++t) binom = binom * (double)(j - 1 - (nn - 1) + t) / (double)t;
-                q = __builtin_fma(Km[m] * binom, dpow[j - nn], q);
+            for (int m = 0; m < MP_MWING; ++m) {
+                const int nn = 2 * m + 2;
+                if (nn <= jj) {
+                    double binom = 1.0;                          // C(jj-1, nn-1), folded at compile time
+                    for (int t = 1; t <= nn - 1; ++t) binom = binom * (double)(jj - 1 - (nn - 1) + t) / (double)t;
+                    Q[jq] = __builtin_fma(Km[m] * binom, dpow[jj - nn], Q[jq]);
+                }
             }
         }
-        q = wave_sum(q);
-        if (lane == 0) rec[MP_Q0 + jq] = q;
     }
-    if (lane == 0) {
-        rec[MP_A] = Ac;
-        rec[MP_B] = Bc;
-        rec[MP_YFAR] = allok ? fmax(100.0 + dmax, 10.0 * dmax) : __builtin_inf();   // inf: never use the expansion
-    }
+#pragma unroll
+    for (int jq = 0; jq < MP_NQ; ++jq) rec[MP_Q0 + jq] = Q[jq];
+    rec[MP_A] = Ac;
+    rec[MP_B] = Bc;
+    rec[MP_YFAR] = allok ? fmax(100.0 + dmax, 10.0 * dmax) : __builtin_inf();   // inf: never use the expansion
 }
 
-// One 64-thread workgroup per (walker, line).  Follows _evaluate_compiled_model's scalar prologue
-// (voigt_model.py:192-200) and _vectorized_voigt_tau's per-line constants (:142-149) operation by
-// operation (the file is compiled with -ffp-contract=off, so nothing here is fused).
-constexpr int PREP_WAVES = 4;        // records per workgroup (one per wave)
-__global__ __launch_bounds__(64 * PREP_WAVES) void prep_lines_kernel(const double* __restrict__ theta, int W, int D,
+// Record preparation, one LANE per record.  Block roles by blockIdx.x:
+//   [0, nb_line)                 line records     index = blockIdx.x * rpw + lane  over (walker, line)
+//   [nb_line, nb_line + nb_cl)   cluster records  index over (walker, cluster)
+//   the rest                     box-prior flags  one lane per walker
+// `rpw` (records per wave, <= 64) spreads a small batch over more CUs; lanes >= rpw idle.
+struct PrepGrid { int rpw, nb_line, nb_cl, nb_flag; };
+__global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict__ theta, int W, int D,
                                                         LinesDev T, const double* __restrict__ lb,
                                                         const double* __restrict__ ub,
                                                         double* __restrict__ lc, int* __restrict__ flags,
                                                         int do_flags, double* __restrict__ lnprob_out,
-                                                        int* __restrict__ genflag) {
+                                                        int* __restrict__ genflag, PrepGrid G) {
     const int nrec = T.L + T.NCm;                     // records per walker: lines, then clusters
-    const int ridx = blockIdx.x * PREP_WAVES + (threadIdx.x >> 6);
-    if (ridx >= W * nrec) return;                     // whole wave
-    const int w = ridx / nrec, l = ridx % nrec;
-    const int lane = threadIdx.x & 63;
-    const double* th = theta + (size_t)w * D;
-    if (l >= T.L) {                                   // ---- multipole record of one cluster ----
-        prep_cluster(th, T, l - T.L, lc + ((size_t)w * nrec + l) * LC_STRIDE, lane);
+    const int lane = threadIdx.x;
+    int blk = blockIdx.x;
+    if (blk < G.nb_line) {
+        const int ridx = blk * G.rpw + lane;
+        if (lane >= G.rpw || ridx >= W * T.L) return;
+        const int w = ridx / T.L, l = ridx - w * T.L;
+        double* rec = lc + ((size_t)w * nrec + l) * LC_STRIDE;
+        const LineScalars s = line_scalars(theta + (size_t)w * D, T, l);
+        const bool xok = (fabs(s.Ax) <= 1.79e308) && (fabs(s.Bx) <= 1.79e308);
+        fill_record(rec, xok ? s.Tl : __builtin_nan(""), s.a);
+        // lines outside the fast domain (a > 0.1, a < 0): their walker goes to the generic kernel
+        if (genflag && (!(s.a >= 0.0) || s.a > 0.1) && (fabs(s.a) <= 1.79e308)) genflag[w] = 1;
+        rec[LC_A] = s.Ax;
+        rec[LC_B] = s.Bx;
+        rec[LC_D] = s.d;
+        rec[LC_RD] = 1.0 / s.d;               // must be the correctly rounded reciprocal (faithful_x)
+        rec[LC_CFD] = s.cfd;
+        rec[LC_FREQ0] = s.freq0;
+        rec[LC_IBF] = s.ibf;
         return;
     }
-    if (do_flags && l == 0) {
-        int oob = 0;
-        for (int d = lane; d < D; d += 64) oob |= (th[d] < lb[d]) || (th[d] > ub[d]);   // vfit_mcmc.py:293
-        const int any = __any(oob);
-        if (lane == 0) {
-            flags[w] = any ? 1 : 0;
-            if (any && lnprob_out) lnprob_out[w] = -__builtin_inf();   // vfit_mcmc.py:350-351
-        }
+    blk -= G.nb_line;
+    if (blk < G.nb_cl) {                              // ---- multipole records ----
+        const int ridx = blk * G.rpw + lane;
+        if (lane >= G.rpw || ridx >= W * T.NCm) return;
+        const int w = ridx / T.NCm, k = ridx - w * T.NCm;
+        prep_cluster(theta + (size_t)w * D, T, k, lc + ((size_t)w * nrec + T.L + k) * LC_STRIDE);
+        return;
     }
-    double* rec = lc + ((size_t)w * nrec + l) * LC_STRIDE;
-    const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
-    // theta row and index tables are fetched concurrently (one memory round trip): lane d holds
-    // theta[d], the three entries are then picked out with a wave shuffle (D <= 64), else by index
-    double thN, thb, thv;
-    if (D <= 64) {
-        const double trow = th[min(lane, D - 1)];
-        thN = __shfl(trow, T.N_idx[l], 64);
-        thb = __shfl(trow, T.b_idx[l], 64);
-        thv = __shfl(trow, T.v_idx[l], 64);
-    } else {
-        thN = th[T.N_idx[l]]; thb = th[T.b_idx[l]]; thv = th[T.v_idx[l]];
-    }
-    const double N = exp10(thN);                       // :192  (10**theta; <= 1 ulp, only scales tau)
-    const double b = thb;                              // :193
-    const double v = thv;                              // :194
-    // quantities that enter x are formed with the reference's operations and roundings ...
-    const double z_total = zf * (1.0 + v / C_KMS) - 1.0;   // :200
-    const double d = 1.0 + z_total;                    // :204
-    const double b_f = b / lam0 * 1e13;                // :142
-    const double freq0 = T.freq0[l];                   // :143  C_FREQ / lambda0, IEEE quotient from the host
-    // ... the others only need ~1e-16 relative accuracy (reciprocal + Newton instead of IEEE division)
-    const double ibf = fast_rcp(b_f);
-    const double constant = ATOMIC_CONSTANT * fast_rcp(freq0 * b);   // :146
-    const double a = gam * (ibf * 0.079577471545947667884);          // :149  gamma / (4 pi b_f)
-    const double Tl = (N * fo) * constant;             // :158
-    const double cfd = C_FREQ * d;
-    const double Ax = cfd * ibf, Bx = freq0 * ibf;
-    const bool xok = (fabs(Ax) <= 1.79e308) && (fabs(Bx) <= 1.79e308);
-    fill_record(rec, lane, xok ? Tl : __builtin_nan(""), a);
-    // lines outside the fast domain (a > 0.1, a < 0): their walker goes to the generic kernel
-    if (genflag && lane == 0 && (!(a >= 0.0) || a > 0.1) && (fabs(a) <= 1.79e308)) genflag[w] = 1;
-    if (lane == 0) {
-        rec[LC_A] = Ax;
-        rec[LC_B] = Bx;
-        rec[LC_D] = d;
-        rec[LC_RD] = 1.0 / d;                 // must be the correctly rounded reciprocal (faithful_x)
-        rec[LC_CFD] = cfd;
-        rec[LC_FREQ0] = freq0;
-        rec[LC_IBF] = ibf;
-    }
+    blk -= G.nb_cl;
+    const int w = blk * 64 + lane;                    // ---- box prior (vfit_mcmc.py:291-295, 350-351) ----
+    if (!do_flags || w >= W) return;
+    const double* th = theta + (size_t)w * D;
+    int oob = 0;
+    for (int d = 0; d < D; ++d) oob |= (th[d] < lb[d]) || (th[d] > ub[d]);
+    flags[w] = oob;
+    if (oob && lnprob_out) lnprob_out[w] = -__builtin_inf();
 }
 
 // Test hook: records for a list of damping parameters with T = 1.
-__global__ __launch_bounds__(64) void prep_h_kernel(const double* __restrict__ a, double* __restrict__ lc) {
-    double* rec = lc + (size_t)blockIdx.x * LC_STRIDE;
-    fill_record(rec, threadIdx.x, 1.0, a[blockIdx.x]);
-    if (threadIdx.x == 0) {
-        rec[LC_A] = 0; rec[LC_B] = 0; rec[LC_D] = 1; rec[LC_RD] = 1; rec[LC_CFD] = 0; rec[LC_FREQ0] = 0; rec[LC_IBF] = 1;
-    }
+__global__ __launch_bounds__(64) void prep_h_kernel(const double* __restrict__ a, int na, double* __restrict__ lc) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= na) return;
+    double* rec = lc + (size_t)i * LC_STRIDE;
+    fill_record(rec, 1.0, a[i]);
+    rec[LC_A] = 0; rec[LC_B] = 0; rec[LC_D] = 1; rec[LC_RD] = 1; rec[LC_CFD] = 0; rec[LC_FREQ0] = 0; rec[LC_IBF] = 1;
 }
 
 struct PixelX {    // x of one pixel for one line, computed from the spectrum grid
