@@ -185,8 +185,8 @@ class vfit:
         context cannot be shared with forked workers, and batching replaces the Pool."""
         if use_pool:
             raise ValueError("use_pool=True is not supported: the batched GPU lnprob replaces the fork Pool")
-        if optimize:
-            raise NotImplementedError("L-BFGS-B pre-optimisation is outside the accelerated path (SURVEY 8f N2)")
+        if optimize:                                   # vfit_mcmc.py:507-512
+            self.theta = self.optimize_guess(self.theta)
         from .sampler import StretchMoveSampler, initialize_walkers
         rng = np.random.default_rng(seed)
         guesses = initialize_walkers(self.theta, self.lb, self.ub, self.no_of_Chain, self.perturbation,

@@ -180,6 +180,9 @@ def test_vfit_mirror_and_compiled_model_on_device():
         s = fit.runmcmc(seed=5)                        # 20 walkers x 30 steps, batched lnprob
         assert fit.samples.shape[1] == 6 and np.all(np.isfinite(s.lnprobability))
         assert fit.best_theta.shape == (6,)
+        lp0 = fit.lnprob(fit.theta)
+        fit.runmcmc(optimize=True, seed=6)             # vfit_mcmc.py:507-512: theta <- optimize_guess(theta)
+        assert fit.lnprob(fit.theta) >= lp0 and np.all(fit.theta >= fit.lb) and np.all(fit.theta <= fit.ub)
     finally:
         fit.close()
 
