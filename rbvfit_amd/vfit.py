@@ -176,6 +176,62 @@ class vfit:
                           bounds=list(zip(self.lb, self.ub)))
         return res.x
 
+    # -- quick fit --------------------------------------------------------------
+    def chi2(self, theta):
+        """Sum over instruments of sum(((flux - model)/error)**2) -- the objective of the reference's
+        quick fit (quick_fit_interface.py:30-53).  (D,) -> float, (W, D) -> (W,); no prior (rows outside
+        the box are evaluated too).  Obtained from the fused likelihood: chi2 = -2 lnlike + sum log w."""
+        th = np.asarray(theta, dtype=np.float64)
+        const = sum(float(np.sum(np.asarray(e["log_inv_sigma2"], dtype=np.float64))) for e in self.instrument_data.values())
+        out = -2.0 * np.atleast_1d(self.lnlike(np.atleast_2d(th))) + const
+        return float(out[0]) if th.ndim == 1 else out
+
+    def estimate_parameter_errors(self, theta_best, theta_initial=None, delta_frac: float = 0.01):
+        """Mirror of ``_estimate_parameter_errors`` (quick_fit_interface.py:87-128): curvature of chi2
+        along each axis from central differences, sigma = 1/sqrt(d2chi2) -- the 2D+1 evaluations are
+        ONE batch.  Non-positive curvature falls back to |theta_best - theta_initial|."""
+        tb = np.asarray(theta_best, dtype=np.float64)
+        ti = np.asarray(self.theta if theta_initial is None else theta_initial, dtype=np.float64)
+        D = tb.size
+        delta = np.maximum(np.maximum(np.abs(tb) * delta_frac, np.abs(ti) * delta_frac), 1e-6)
+        batch = np.vstack([tb[None, :], tb[None, :] + np.diag(delta), tb[None, :] - np.diag(delta)])
+        c = self.chi2(batch)
+        d2 = (c[1:D + 1] - 2.0 * c[0] + c[D + 1:]) / delta ** 2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            err = np.where(d2 > 0, np.sqrt(1.0 / d2), np.abs(tb - ti))
+        return err
+
+    def fit_quick(self, verbose: bool = False, eps: float = 1e-8):
+        """Mirror of ``vfit.fit_quick`` (vfit_mcmc.py:362-406 -> quick_fit_interface.py:10-84):
+        L-BFGS-B on chi2 inside the bounds (``maxfun=5000``), then curvature errors.  The
+        finite-difference gradient scipy would build serially is one (D+1)-row GPU batch per
+        iteration.  Returns (theta_best, theta_best_error) and stores them on the object."""
+        import warnings
+        import scipy.optimize as op
+        self.mcmc_flag = False
+        lb, ub = self.lb, self.ub
+
+        def objective(th):
+            h = np.where(th + eps > ub, -eps, eps)
+            c = self.chi2(np.vstack([th[None, :], th[None, :] + np.diag(h)]))
+            if not np.all(np.isfinite(c)):
+                return 1e10, np.zeros_like(th)               # quick_fit_interface.py:51-53
+            return float(c[0]), (c[1:] - c[0]) / h
+
+        try:
+            res = op.minimize(objective, np.asarray(self.theta, dtype=np.float64), jac=True, method="L-BFGS-B",
+                              bounds=list(zip(lb, ub)), options={"maxfun": 5000})
+            theta_best = res.x
+            theta_err = self.estimate_parameter_errors(theta_best, self.theta)
+            if not res.success:
+                warnings.warn(f"Optimization may not have converged: {res.message}")
+        except Exception as e:                                # quick_fit_interface.py:79-82
+            warnings.warn(f"Minimize fitting failed: {e}")
+            theta_best = np.array(self.theta, dtype=np.float64)
+            theta_err = np.zeros_like(theta_best)
+        self.theta_best, self.theta_best_error = theta_best, theta_err
+        return theta_best, theta_err
+
     # -- walker loop (host) ----------------------------------------------------------------------
     def runmcmc(self, optimize: bool = False, verbose: bool = False, use_pool: bool = False, seed=None):
         """Mirror of ``vfit.runmcmc`` (vfit_mcmc.py:492-561) reduced to the sampling itself: walker

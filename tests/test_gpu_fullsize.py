@@ -245,6 +245,21 @@ def test_components_and_batched_gradient():
         best = fit.optimize_guess(t0)
         assert np.all(best >= z["lb"]) and np.all(best <= z["ub"])
         assert fit.lnprob(best) >= fit.lnprob(t0)
+        # quick fit (vfit_mcmc.py:362-406, quick_fit_interface.py): chi2 objective, curvature errors
+        insts = vo.instruments_from_fixture(z)
+        rows = np.vstack([z["thetas"][:5], z["lb"][None, :] - 0.1])          # incl. a row outside the box
+        ref_chi2 = np.array([sum(np.sum(((i.flux - vo.model_flux(i.data, r, i.wave)) / z["G__error"]) ** 2) for i in insts)
+                             for r in rows])
+        np.testing.assert_allclose(fit.chi2(rows), ref_chi2, rtol=1e-9)
+        assert isinstance(fit.chi2(rows[0]), float)
+        tb, terr = fit.fit_quick()
+        assert tb.shape == (6,) and terr.shape == (6,) and np.all(terr > 0) and np.all(np.isfinite(terr))
+        assert fit.chi2(tb) <= fit.chi2(np.asarray(fit.theta)) + 1e-6
+        # errors = 1/sqrt(curvature): redo one axis serially with the oracle
+        k, d = 2, max(abs(tb[2]) * 0.01, abs(fit.theta[2]) * 0.01, 1e-6)
+        c = [sum(np.sum(((i.flux - vo.model_flux(i.data, tb + s * d * np.eye(6)[k], i.wave)) / z["G__error"]) ** 2)
+                 for i in insts) for s in (0, 1, -1)]
+        np.testing.assert_allclose(terr[k], np.sqrt(d * d / (c[1] - 2 * c[0] + c[2])), rtol=1e-5)
     finally:
         fit.close()
 

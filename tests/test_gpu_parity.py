@@ -91,3 +91,46 @@ def test_repeated_calls_with_changing_theta_are_fresh():
             singles = np.array([eng.lnprob(th[i])[0] for i in k])
             assert np.array_equal(got[k], singles)
         assert np.array_equal(eng.lnprob(base), ref_first)
+
+
+def test_context_usable_from_other_threads():
+    """SURVEY 8(b) threading: the GUI calls runmcmc from a QThread (gui/fitting_tab.py:51-77); a
+    context created on one thread must serve calls from others, one at a time (internal mutex)."""
+    import threading
+    z = load_golden("c0_mgii")
+    eng = engine_from_fixture(z)
+    try:
+        ref = eng.lnprob(z["thetas"])
+        results, errors = {}, []
+
+        def work(k):
+            try:
+                for _ in range(20):
+                    results[k] = eng.lnprob(z["thetas"][k::4])
+            except Exception as e:                              # pragma: no cover
+                errors.append(e)
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors
+        for k in range(4):
+            assert np.array_equal(results[k], ref[k::4], equal_nan=True)
+    finally:
+        eng.close()
+
+
+def test_fork_guard_raises_in_child():
+    """Not fork-safe: a child created by fork() must get an error, not a GPU fault."""
+    import os
+    z = load_golden("one_px")
+    eng = engine_from_fixture(z)
+    try:
+        eng._pid = os.getpid() + 1                              # what a forked child would see
+        with pytest.raises(RuntimeError, match="fork"):
+            eng.lnprob(z["thetas"])
+    finally:
+        eng._pid = os.getpid()
+        eng.close()
