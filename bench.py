@@ -284,6 +284,14 @@ def main():
         host_lat = dict(median_us=1e6 * float(np.median(lat)), p10_us=1e6 * float(lat[10]), p90_us=1e6 * float(lat[90]),
                         calls=100, walkers_per_call=W)
 
+        # the walker loop itself on the GPU (vp_stretch_run): real ensemble steps per second, two
+        # half-ensemble passes per step, proposals and accept/reject in HBM -- not part of `value`
+        nst = 300
+        wl.engine.stretch_run(wl.thetas, 20, seed=1, store_chain=False)
+        ts0 = time.perf_counter()
+        wl.engine.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
+        sampler_steps = nst / (time.perf_counter() - ts0)
+
     result = d_out.cpu().numpy()
     if rank == 0:
         evals = W * world * args.steps
@@ -299,6 +307,7 @@ def main():
             "mcmc_steps_per_sec": (evals / elapsed) / (W * world),
             "host_entry_evals_per_sec_pcie_inclusive": host_rate,
             "host_entry_latency": host_lat,
+            "device_sampler_steps_per_sec": sampler_steps,
             "roofline": roof,
         }
         if use_dist:

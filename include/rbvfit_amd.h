@@ -41,7 +41,8 @@ enum {
     VP_EINVAL = 1,      /* bad argument (shape, index out of range, NULL) */
     VP_EHIP = 2,        /* a HIP runtime call failed */
     VP_ESTATE = 3,      /* call order (e.g. lnprob before bounds/instruments are set) */
-    VP_ENOMEM = 4
+    VP_ENOMEM = 4,
+    VP_ENAN = 5      /* a proposal's lnprob was NaN (vp_stretch_run) */
 };
 
 /* LSF dispatch branches of core/voigt_model.py:220-230 */
@@ -118,6 +119,25 @@ int vp_model_flux_components(vp_ctx* ctx, int inst, int W, int D, const double* 
  * core/voigt_model.py:156: the production tier logic is used (tier chosen per wavefront = 64
  * consecutive x_j of one a_i). */
 int vp_voigt_h(vp_ctx* ctx, int na, const double* a, int nx, const double* x, double* out);
+
+/* Device-resident ensemble sampler.  Replaces: the walker loop the reference delegates to emcee
+ * (vfit_mcmc.py:408-423 EnsembleSampler construction, :536-540 run_mcmc): `nsteps` iterations of
+ * the affine-invariant stretch move (scale `a`, emcee's default 2.0) in red-blue form -- each
+ * half-ensemble is proposed, evaluated (one lnprob batch in HBM) and accepted/rejected on the
+ * GPU; nothing crosses PCIe until the call returns.
+ *   pos        (W, D) host, in: start positions, out: final positions.   W even, W >= 2.
+ *   lnprob     (W) host, in (when have_lnprob != 0) / out: lnprob of pos.
+ *   seed/step0 Philox4x32-10 key and the index of the first step: draws are a pure function of
+ *              (seed, step, half, walker), so run(n1) then run(n2, step0 = n1) equals run(n1 + n2).
+ *   chain      (nsteps, W, D) host or NULL;  chain_lnprob (nsteps, W) host or NULL: state after each step.
+ *   naccepted  (W) host or NULL: accepted proposals per walker, ADDED to the values passed in.
+ * Returns VP_ENAN (state and outputs undefined) if a proposal's lnprob is NaN -- emcee raises
+ * "Probability function returned NaN" there. */
+int vp_stretch_run(vp_ctx* ctx, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
+                   uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted);
+
+/* Philox4x32-10 block function used by vp_stretch_run (host evaluation; known-answer tests). */
+void vp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 /* Optional per-kernel timing with HIP events recorded on the stream the kernels are launched on
  * (used by bench.py for the roofline figure).  While enabled, every lnprob batch records events

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RBVFIT_AMD_LIB") or os.path.join(_HERE, "lib", "librbvfit_amd.so")
 
-VP_OK, VP_EINVAL, VP_EHIP, VP_ESTATE, VP_ENOMEM = 0, 1, 2, 3, 4
+VP_OK, VP_EINVAL, VP_EHIP, VP_ESTATE, VP_ENOMEM, VP_ENAN = 0, 1, 2, 3, 4, 5
 LSF_NONE, LSF_SCIPY_NEAREST, LSF_ASTROPY_EXTEND = 0, 1, 2
 VOIGT_WOFZ, VOIGT_FAST = 0, 1
 
@@ -48,6 +48,9 @@ SIGNATURES = {
                                              C.c_int, C.c_void_p]),
     "vp_model_flux_components": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "vp_voigt_h": (C.c_int, [_ctx, C.c_int, _dp, C.c_int, _dp, _dp]),
+    "vp_stretch_run": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
+                                 _dp, _dp, C.POINTER(C.c_int64)]),
+    "vp_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vp_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "vp_profile_read": (C.c_int, [_ctx, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "vp_num_instruments": (C.c_int, [_ctx]),

@@ -2,6 +2,7 @@
 // residency of the static data, workspace, launches.  No torch types, no Python.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 
 #include "../../include/rbvfit_amd.h"
 #include "voigt_kernels.h"
+#include "sampler_kernels.h"
 
 namespace {
 
@@ -566,6 +568,79 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     return VP_OK;
+}
+
+int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
+                   uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted) {
+    int rc = check_batch_args(c, W, D, pos, lnprob);
+    if (rc) return rc;
+    if (W < 2 || (W & 1)) return fail(c, VP_EINVAL, "vp_stretch_run: the number of walkers must be even and >= 2");
+    if (nsteps < 0 || !(a > 1.0)) return fail(c, VP_EINVAL, "vp_stretch_run: nsteps must be >= 0 and a > 1");
+    if ((chain == nullptr) != (chain_lnprob == nullptr)) return fail(c, VP_EINVAL, "vp_stretch_run: chain and chain_lnprob go together");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, W))) return rc;
+    hipStream_t s = c->stream;
+    const int half = W / 2;
+    // device state: pos (W,D) | lp (W) | prop (half,D) | lp_new (half) | zz (half) | nacc (W) | nanflag | chain chunk
+    const size_t nd_state = (size_t)W * D + W + (size_t)half * D + 2 * (size_t)half;
+    const size_t row = (size_t)W * (D + 1);                       // doubles stored per step
+    size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
+    const size_t bytes = (nd_state + chunk * row) * sizeof(double) + (size_t)W * sizeof(long long) + 64;
+    if ((rc = ensure_scratch(c, bytes))) return rc;
+    double* d_pos = c->d_scratch;
+    double* d_lp = d_pos + (size_t)W * D;
+    double* d_prop = d_lp + W;
+    double* d_lpnew = d_prop + (size_t)half * D;
+    double* d_zz = d_lpnew + half;
+    double* d_chain = d_zz + half;                                // chunk * (W*D) then chunk * W
+    long long* d_nacc = reinterpret_cast<long long*>(d_chain + chunk * row);
+    int* d_nan = reinterpret_cast<int*>(d_nacc + W);
+    HIP_TRY(c, hipMemcpyAsync(d_pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(d_nacc, 0, (size_t)W * sizeof(long long) + sizeof(int), s));
+    if (have_lnprob) HIP_TRY(c, hipMemcpyAsync(d_lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, s));
+    else if ((rc = enqueue_lnprob(c, W, d_pos, d_lp, s))) return rc;
+    const int thr = 64;
+    for (int done = 0; done < nsteps;) {
+        const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
+        for (int it = 0; it < n; ++it) {
+            const uint64_t step = step0 + (uint64_t)(done + it);
+            for (int h = 0; h < 2; ++h) {
+                const int s0 = h ? half : 0, c0 = h ? 0 : half;
+                hipLaunchKernelGGL(vp::stretch_propose_kernel, dim3((half + thr - 1) / thr), dim3(thr), 0, s, d_pos, D, s0, half,
+                                   c0, half, a, seed, step, h, d_prop, d_zz);
+                if ((rc = enqueue_lnprob(c, half, d_prop, d_lpnew, s))) return rc;
+                const bool store = chain && h == 1;
+                hipLaunchKernelGGL(vp::stretch_accept_kernel, dim3((W + thr - 1) / thr), dim3(thr), 0, s, d_pos, d_lp, d_prop,
+                                   d_lpnew, d_zz, W, D, s0, half, seed, step, h, d_nacc, d_nan,
+                                   store ? d_chain + (size_t)it * W * D : (double*)nullptr,
+                                   store ? d_chain + chunk * (size_t)W * D + (size_t)it * W : (double*)nullptr);
+            }
+        }
+        HIP_TRY(c, hipGetLastError());
+        if (chain) {
+            HIP_TRY(c, hipMemcpyAsync(chain + (size_t)done * W * D, d_chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(chain_lnprob + (size_t)done * W, d_chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
+                                      hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
+        done += n;
+    }
+    std::vector<long long> h_nacc(W);
+    int h_nan = 0;
+    HIP_TRY(c, hipMemcpyAsync(pos, d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(lnprob, d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(h_nacc.data(), d_nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&h_nan, d_nan, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (naccepted) for (int w = 0; w < W; ++w) naccepted[w] += (int64_t)h_nacc[w];
+    if (h_nan) return fail(c, VP_ENAN, "vp_stretch_run: Probability function returned NaN");
+    return VP_OK;
+}
+
+void vp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    const vp::Philox4 r = vp::philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
 }
 
 int vp_voigt_h(vp_ctx* c, int na, const double* a, int nx, const double* x, double* out) {

@@ -1,0 +1,99 @@
+// Device-resident stretch-move ensemble sampler: the walker loop the reference
+// delegates to emcee (vfit_mcmc.py:408-423, 536-540), with positions, lnprob, proposals and
+// accept/reject kept in HBM.  Goodman & Weare (2010) stretch move in emcee's red-blue form: the
+// ensemble is split in two halves and each half is updated against the other with ONE lnprob batch.
+//
+// Randomness: Philox4x32-10 (Salmon et al. 2011), counter-based -- the draw for (step, half, walker,
+// purpose) is a pure function of the seed, so a run is reproducible and can be split into calls.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vp {
+
+struct Philox4 { uint32_t v[4]; };
+
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+// 53-bit uniform in [0, 1) from two 32-bit words
+__host__ __device__ inline double u01(uint32_t hi, uint32_t lo) {
+    const uint64_t x = (((uint64_t)hi << 32) | lo) >> 11;
+    return (double)x * (1.0 / 9007199254740992.0);
+}
+
+// counter layout: (walker, step low, step high | half << 31, purpose)
+__device__ inline Philox4 draw(uint64_t seed, uint64_t step, int half, int walker, uint32_t purpose) {
+    return philox4x32_10((uint32_t)walker, (uint32_t)step, (uint32_t)(step >> 32) | ((uint32_t)half << 31), purpose,
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// Proposal for the nS walkers of half S (rows [s0, s0+nS)) against the complementary rows [c0, c0+nC):
+//   z ~ g(z) ∝ 1/sqrt(z) on [1/a, a]:  z = ((a-1) u + 1)^2 / a;   Y = X_j + z (X_k - X_j)
+__global__ void stretch_propose_kernel(const double* __restrict__ pos, int D, int s0, int nS, int c0, int nC, double a,
+                                       uint64_t seed, uint64_t step, int half, double* __restrict__ prop,
+                                       double* __restrict__ zz) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nS) return;
+    const Philox4 r = draw(seed, step, half, s0 + k, 0u);
+    const double u1 = u01(r.v[0], r.v[1]), u2 = u01(r.v[2], r.v[3]);
+    const double t = (a - 1.0) * u1 + 1.0;
+    const double z = t * t / a;
+    int j = (int)(u2 * (double)nC);
+    j = j < nC - 1 ? j : nC - 1;
+    const double* __restrict__ x = pos + (size_t)(s0 + k) * D;
+    const double* __restrict__ c = pos + (size_t)(c0 + j) * D;
+    double* __restrict__ y = prop + (size_t)k * D;
+    for (int d = 0; d < D; ++d) y[d] = c[d] - (c[d] - x[d]) * z;
+    zz[k] = z;
+}
+
+// Accept/reject for half S and, when chain_pos != nullptr, storage of the whole ensemble's state
+// (row `w` is handled by thread w; rows outside S are only stored).
+//   ln q = (D-1) ln z + lnprob(Y) - lnprob(X);  accept when ln u < ln q.   NaN lnprob(Y) -> flag (emcee raises).
+__global__ void stretch_accept_kernel(double* __restrict__ pos, double* __restrict__ lp, const double* __restrict__ prop,
+                                      const double* __restrict__ lp_new, const double* __restrict__ zz, int W, int D,
+                                      int s0, int nS, uint64_t seed, uint64_t step, int half,
+                                      long long* __restrict__ nacc, int* __restrict__ nanflag,
+                                      double* __restrict__ chain_pos, double* __restrict__ chain_lp) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    double* __restrict__ x = pos + (size_t)w * D;
+    const int k = w - s0;
+    if (k >= 0 && k < nS) {
+        const double ln = lp_new[k];
+        if (ln != ln) {
+            atomicExch(nanflag, 1);
+        } else {
+            const Philox4 r = draw(seed, step, half, w, 1u);
+            const double u = u01(r.v[0], r.v[1]);
+            const double lnq = (double)(D - 1) * log(zz[k]) + ln - lp[w];
+            if (log(u) < lnq) {
+                const double* __restrict__ y = prop + (size_t)k * D;
+                for (int d = 0; d < D; ++d) x[d] = y[d];
+                lp[w] = ln;
+                nacc[w] += 1;
+            }
+        }
+    }
+    if (chain_pos) {
+        double* __restrict__ o = chain_pos + (size_t)w * D;
+        for (int d = 0; d < D; ++d) o[d] = x[d];
+        chain_lp[w] = lp[w];
+    }
+}
+
+}  // namespace vp

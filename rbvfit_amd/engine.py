@@ -170,6 +170,34 @@ class Engine:
         self._check(self._lib.vp_voigt_h(self._ctx, a.size, _dp(a), x.size, _dp(x), _dp(out)))
         return out
 
+    # -- device-resident ensemble sampler (vp_stretch_run) ---------------------------------------
+    def stretch_run(self, pos, nsteps: int, lnprob=None, a: float = 2.0, seed: int = 0, step0: int = 0,
+                    store_chain: bool = True, naccepted=None):
+        """``nsteps`` stretch-move iterations on the GPU (positions, lnprob, proposals and
+        accept/reject stay in HBM).  Returns (pos, lnprob, chain, chain_lnprob, naccepted);
+        chain arrays are None when ``store_chain`` is False.  Raises ValueError when a proposal's
+        lnprob is NaN, as emcee does."""
+        self._guard()
+        pos = np.array(pos, dtype=np.float64, order="C")
+        if pos.ndim != 2:
+            raise ValueError("pos must have shape (nwalkers, ndim)")
+        W, D = pos.shape
+        have = lnprob is not None
+        lp = np.array(lnprob, dtype=np.float64) if have else np.empty(W, dtype=np.float64)
+        if lp.shape != (W,):
+            raise ValueError("lnprob must have shape (nwalkers,)")
+        chain = np.empty((nsteps, W, D), dtype=np.float64) if store_chain else None
+        clp = np.empty((nsteps, W), dtype=np.float64) if store_chain else None
+        nacc = np.zeros(W, dtype=np.int64) if naccepted is None else np.ascontiguousarray(naccepted, dtype=np.int64)
+        rc = self._lib.vp_stretch_run(self._ctx, W, D, _dp(pos), _dp(lp), 1 if have else 0, int(nsteps), float(a),
+                                      C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint64(int(step0)),
+                                      _dp(chain) if store_chain else None, _dp(clp) if store_chain else None,
+                                      nacc.ctypes.data_as(C.POINTER(C.c_int64)))
+        if rc == L.VP_ENAN:
+            raise ValueError("Probability function returned NaN")
+        self._check(rc)
+        return pos, lp, chain, clp, nacc
+
     # -- per-kernel timing (HIP events on the launch stream) ------------------------------------
     def profile_enable(self, on: bool = True):
         self._guard()

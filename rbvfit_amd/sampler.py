@@ -89,3 +89,42 @@ class StretchMoveSampler:
     def get_chain(self, discard: int = 0, flat: bool = False):
         c = self.chain[discard:]
         return c.reshape(-1, self.ndim) if flat else c
+
+
+class DeviceStretchSampler:
+    """Same interface as ``StretchMoveSampler``, but the whole loop runs on the GPU through
+    ``vp_stretch_run`` (include/rbvfit_amd.h): positions, lnprob, proposals and accept/reject stay
+    in HBM, one lnprob batch per half-ensemble, Philox4x32-10 draws keyed by (seed, step, half,
+    walker) -- successive ``run_mcmc`` calls continue the same stream.  ``engine`` is the
+    ``rbvfit_amd.Engine`` that holds the bounds and instruments (``vfit.engine``)."""
+
+    def __init__(self, nwalkers: int, ndim: int, engine, a: float = 2.0, seed: Optional[int] = None):
+        if nwalkers % 2 or nwalkers < 2 * ndim:
+            raise ValueError("nwalkers must be even and at least 2*ndim (as emcee requires)")
+        self.nwalkers, self.ndim, self.engine, self.a = nwalkers, ndim, engine, float(a)
+        self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+        self.chain = None
+        self.lnprobability = None
+        self.naccepted = np.zeros(nwalkers, dtype=np.int64)
+        self.nsteps = 0
+
+    def run_mcmc(self, p0, nsteps: int, lnprob0=None, store: bool = True):
+        pos = np.array(p0, dtype=np.float64)
+        if pos.shape != (self.nwalkers, self.ndim):
+            raise ValueError(f"initial state must have shape ({self.nwalkers}, {self.ndim})")
+        pos, lp, chain, lnps, self.naccepted = self.engine.stretch_run(
+            pos, nsteps, lnprob=lnprob0, a=self.a, seed=self.seed, step0=self.nsteps, store_chain=store,
+            naccepted=self.naccepted)
+        if store:
+            self.chain = chain if self.chain is None else np.concatenate([self.chain, chain])
+            self.lnprobability = lnps if self.lnprobability is None else np.concatenate([self.lnprobability, lnps])
+        self.nsteps += nsteps
+        return pos, lp
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted / max(self.nsteps, 1)
+
+    def get_chain(self, discard: int = 0, flat: bool = False):
+        c = self.chain[discard:]
+        return c.reshape(-1, self.ndim) if flat else c

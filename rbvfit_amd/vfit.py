@@ -233,11 +233,13 @@ class vfit:
         return theta_best, theta_err
 
     # -- walker loop (host) ----------------------------------------------------------------------
-    def runmcmc(self, optimize: bool = False, verbose: bool = False, use_pool: bool = False, seed=None):
+    def runmcmc(self, optimize: bool = False, verbose: bool = False, use_pool: bool = False, seed=None,
+                sampler: str = "auto"):
         """Mirror of ``vfit.runmcmc`` (vfit_mcmc.py:492-561) reduced to the sampling itself: walker
         initialisation (:442-466) and ``no_of_steps`` ensemble steps with ONE batched GPU lnprob
-        call per half-ensemble.  emcee is used with ``vectorize=True`` when it is installed,
-        otherwise ``rbvfit_amd.sampler.StretchMoveSampler``.  ``use_pool`` must stay False: a HIP
+        call per half-ensemble.  ``sampler``: 'emcee' (``vectorize=True``), 'host'
+        (``rbvfit_amd.sampler.StretchMoveSampler``), 'device' (``DeviceStretchSampler``: the whole
+        loop in HBM) or 'auto' (emcee when installed, else 'host').  ``use_pool`` must stay False: a HIP
         context cannot be shared with forked workers, and batching replaces the Pool."""
         if use_pool:
             raise ValueError("use_pool=True is not supported: the batched GPU lnprob replaces the fork Pool")
@@ -247,11 +249,23 @@ class vfit:
         rng = np.random.default_rng(seed)
         guesses = initialize_walkers(self.theta, self.lb, self.ub, self.no_of_Chain, self.perturbation,
                                      self.lnprob, rng)
-        try:
-            import emcee  # noqa: F401
+        if sampler not in ("auto", "emcee", "host", "device"):
+            raise ValueError("sampler must be 'auto', 'emcee', 'host' or 'device'")
+        if sampler == "auto":
+            try:
+                import emcee  # noqa: F401
+                sampler = "emcee"
+            except ImportError:
+                sampler = "host"
+        if sampler == "emcee":
+            import emcee
             sampler = emcee.EnsembleSampler(self.no_of_Chain, self.ndim, self.lnprob, vectorize=True)
             sampler.run_mcmc(guesses, self.no_of_steps, progress=verbose)
-        except ImportError:
+        elif sampler == "device":                      # whole walker loop on the GPU (vp_stretch_run)
+            from .sampler import DeviceStretchSampler
+            sampler = DeviceStretchSampler(self.no_of_Chain, self.ndim, self.engine, seed=seed)
+            sampler.run_mcmc(guesses, self.no_of_steps)
+        else:
             sampler = StretchMoveSampler(self.no_of_Chain, self.ndim, self.lnprob, seed=seed)
             sampler.run_mcmc(guesses, self.no_of_steps)
         self.sampler = sampler

@@ -160,3 +160,39 @@ def test_initialize_walkers_redraws_non_finite_rows():
     with pytest.raises(RuntimeError):
         initialize_walkers([0.5, 0.5], lb, ub, 8, 0.1, lambda th: np.full(len(th), -np.inf),
                            np.random.default_rng(1), max_attempts=3)
+
+
+# ---- Philox4x32-10 of the device sampler (host evaluation of the same function) -----------------
+def _philox_py(ctr, key):
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c, k = list(ctr), list(key)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & mask, (p0 >> 32) ^ c[3] ^ k[1], p0 & mask]
+        k = [(k[0] + W0) & mask, (k[1] + W1) & mask]
+    return c
+
+
+def _philox_lib(ctr, key):
+    import ctypes as C
+    from rbvfit_amd import _lib
+    lib = _lib.load()
+    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    lib.vp_philox4x32(c, k, o)
+    return list(o)
+
+
+def test_philox4x32_known_answers_and_python_restatement():
+    # Random123 known-answer vectors for philox4x32-10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kat:
+        assert tuple(_philox_py(ctr, key)) == out
+        assert tuple(_philox_lib(ctr, key)) == out
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        ctr = [int(v) for v in rng.integers(0, 2 ** 32, 4)]
+        key = [int(v) for v in rng.integers(0, 2 ** 32, 2)]
+        assert _philox_lib(ctr, key) == _philox_py(ctr, key)
