@@ -21,6 +21,7 @@ thread_local std::string g_create_error;
 
 struct Instrument {
     vp::InstDev dev{};
+    vp::InstDev dev_s{};         // same instrument, one-pass tiles: used for small batches (lnprob only)
     vp::LinesDev lines{};
     double sum_logw = 0.0;
     std::vector<void*> allocs;   // device allocations owned by this instrument
@@ -58,10 +59,11 @@ struct vp_ctx {
     unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int* d_genflag = nullptr;    // (capW) walkers with lines outside the fast domain (per instrument pass)
     std::vector<double> h_lb;    // host copy of the lower bounds
-    int* d_tile_off = nullptr;   // (n_inst + 1)
+    int* d_tile_off = nullptr;   // 2 x (n_inst + 1): tile offsets of the full-size and of the one-pass geometry
     double* d_sum_logw = nullptr;
     bool meta_dirty = true;
-    int total_tiles = 0;
+    int total_tiles = 0;         // max over the two geometries (workspace size)
+    int total_tiles_g[2] = {0, 0};
     double* h_pinned = nullptr;  // staging for theta / out
     size_t h_pinned_bytes = 0;
     // model_flux / voigt_h scratch
@@ -131,13 +133,17 @@ int ensure_workspace(vp_ctx* c, int W) {
     int maxL = 1;
     for (auto& in : c->inst) maxL = std::max(maxL, in.dev.L + in.dev.NCm);
     if (c->meta_dirty) {
-        std::vector<int> off(c->inst.size() + 1, 0);
-        std::vector<double> slw(c->inst.size() + 1, 0.0);
+        const size_t n1 = c->inst.size() + 1;
+        std::vector<int> off(2 * n1, 0);
+        std::vector<double> slw(n1, 0.0);
         for (size_t k = 0; k < c->inst.size(); ++k) {
             off[k + 1] = off[k] + c->inst[k].dev.ntiles;
+            off[n1 + k + 1] = off[n1 + k] + c->inst[k].dev_s.ntiles;
             slw[k] = c->inst[k].sum_logw;
         }
-        c->total_tiles = off.back();
+        c->total_tiles_g[0] = off[n1 - 1];
+        c->total_tiles_g[1] = off[2 * n1 - 1];
+        c->total_tiles = std::max(c->total_tiles_g[0], c->total_tiles_g[1]);
         if (c->d_tile_off) HIP_TRY(c, hipFree(c->d_tile_off));
         if (c->d_sum_logw) HIP_TRY(c, hipFree(c->d_sum_logw));
         HIP_TRY(c, hipMalloc((void**)&c->d_tile_off, off.size() * sizeof(int)));
@@ -169,15 +175,16 @@ int ensure_workspace(vp_ctx* c, int W) {
 
 template <int OUT, bool GENERIC>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
-                 int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag) {
-    dim3 grid(W, in.dev.ntiles);
+                 int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag, const vp::InstDev* geom = nullptr) {
+    const vp::InstDev& dev = geom ? *geom : in.dev;
+    dim3 grid(W, dev.ntiles);
     dim3 block(64 * in.nwaves);
-    if (in.dev.method == VP_VOIGT_FAST) {
+    if (dev.method == VP_VOIGT_FAST) {
         if (!GENERIC)
-            hipLaunchKernelGGL((vp::tile_kernel<1, OUT, false>), grid, block, in.lds_bytes, s, in.dev, lc, flags, out,
+            hipLaunchKernelGGL((vp::tile_kernel<1, OUT, false>), grid, block, in.lds_bytes, s, dev, lc, flags, out,
                                stride, offset, fin, genflag);
     } else {
-        hipLaunchKernelGGL((vp::tile_kernel<0, OUT, GENERIC>), grid, block, in.lds_bytes, s, in.dev, lc, flags, out,
+        hipLaunchKernelGGL((vp::tile_kernel<0, OUT, GENERIC>), grid, block, in.lds_bytes, s, dev, lc, flags, out,
                            stride, offset, fin, genflag);
     }
 }
@@ -229,7 +236,13 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     int tile_off = 0;
     const bool prof = c->profiling;
     size_t m0 = prof ? prof_mark(c, s) : 0;
-    const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off, c->d_sum_logw, d_out, (int)c->inst.size(), c->total_tiles,
+    // Geometry: a batch whose full-size tiles would leave most wave slots empty is cut into one-pass
+    // tiles instead (twice the workgroups, half the per-wave latency): measured better up to 256
+    // walkers x 12 tiles and worse from 384 x 12 on (256 CUs x 4 SIMDs x 5 waves = 5120 slots).
+    int sel = ((long)W * c->total_tiles_g[0] <= 3840) ? 1 : 0;
+    if (const char* e = getenv("RBVFIT_AMD_GEOM")) sel = atoi(e) ? 1 : 0;
+    const int ntot = c->total_tiles_g[sel];
+    const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw, d_out, (int)c->inst.size(), ntot,
                                c->d_stamps};
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
@@ -237,17 +250,18 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
         launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr, s);
         size_t m1 = prof ? prof_mark(c, s) : 0;
-        launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin,
-                              gen ? c->d_genflag : (const int*)nullptr);
+        const vp::InstDev& geom = sel ? in.dev_s : in.dev;
+        launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin,
+                              gen ? c->d_genflag : (const int*)nullptr, &geom);
         if (gen)
-            launch_tile<0, true>(in, c->d_lc, c->d_flags, c->d_partial, c->total_tiles, tile_off, W, s, fin, c->d_genflag);
+            launch_tile<0, true>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin, c->d_genflag, &geom);
         if (prof) {
             size_t m2 = prof_mark(c, s);
             c->spans.push_back({m0, m1, 0});
             c->spans.push_back({m1, m2, 1});
             m0 = m2;
         }
-        tile_off += in.dev.ntiles;
+        tile_off += geom.ntiles;
     }
     HIP_TRY(c, hipGetLastError());
     return VP_OK;
@@ -426,6 +440,14 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
+    in.dev_s = d;                                        // one-pass tiles for small batches (same LDS layout rules)
+    {
+        const int span_s = 64 * vp::RB * nwaves;
+        if (span_s < d.span && span_s - (Kuse - 1) >= 64) {
+            in.dev_s.span = span_s; in.dev_s.TP = span_s - (Kuse - 1);
+            in.dev_s.ntiles = (P + in.dev_s.TP - 1) / in.dev_s.TP;
+        }
+    }
     in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES + Kuse + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
     in.h_lambda0.assign(lambda0, lambda0 + L); in.h_gamma.assign(gamma, gamma + L); in.h_bidx.assign(b_idx, b_idx + L);

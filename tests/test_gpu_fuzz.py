@@ -1,6 +1,8 @@
 """Seeded random configurations (lines, components, redshifts, grids, LSFs, theta) on the GPU vs the
 oracle: exercises tier boundaries, mixed chunks, clusters of any size, descending / non-uniform
 wavelength grids, very narrow and very broad lines, saturated and damped profiles."""
+import os
+
 import numpy as np
 import pytest
 
@@ -76,9 +78,15 @@ def test_random_configuration(seed):
         e.set_bounds(lb, ub)
         e.add_instrument(wave, flux, inst.inv_sigma2, inst.log_inv_sigma2, **data.engine_kwargs())
         got = e.lnprob(thetas)
+        os.environ["RBVFIT_AMD_GEOM"] = "0"              # the two-pass tile geometry (large batches) as well
+        try:
+            got_big = e.lnprob(thetas)
+        finally:
+            del os.environ["RBVFIT_AMD_GEOM"]
         fl = e.model_flux(0, thetas[:3])
         un = e.model_flux(0, thetas[:2], convolved=False)
     np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    np.testing.assert_allclose(got_big, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     for i in range(3):
         np.testing.assert_allclose(fl[i], vo.model_flux(od, thetas[i], wave), rtol=0, atol=FLUX_ATOL)
     for i in range(2):

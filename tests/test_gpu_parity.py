@@ -15,9 +15,12 @@ def oracle():
     return vo
 
 
+@pytest.mark.parametrize("geom", ["auto", "0", "1"])      # tile geometry: by batch size / two-pass / one-pass tiles
 @pytest.mark.parametrize("name", golden_cases())
-def test_lnprob_matches_golden(name):
+def test_lnprob_matches_golden(name, geom, monkeypatch):
     z = load_golden(name)
+    if geom != "auto":
+        monkeypatch.setenv("RBVFIT_AMD_GEOM", geom)
     with engine_from_fixture(z) as eng:
         got = eng.lnprob(z["thetas"])
     ref = z["lnprob"]
