@@ -448,7 +448,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
             in.dev_s.ntiles = (P + in.dev_s.TP - 1) / in.dev_s.TP;
         }
     }
-    in.lds_bytes = (size_t)(span + 4 + vp::DAW_LDS_DOUBLES + Kuse + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
+    in.lds_bytes = (size_t)(span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + ((Kuse + 7) & ~7) + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
     in.h_lambda0.assign(lambda0, lambda0 + L); in.h_gamma.assign(gamma, gamma + L); in.h_bidx.assign(b_idx, b_idx + L);
     analyse_generic(c, in);

@@ -64,6 +64,17 @@ constexpr double ALG916_C = 0.329973702884629072537;   // (2/pi) * h
 constexpr double INV_SQRT_PI = 0.56418958354775628694807945156;
 constexpr double X_CORE = 8.0;     // |x| below this: line-core evaluation
 
+// a*b + c with the wave-uniform addend c taken from an SGPR pair.  For a Horner step with a uniform
+// coefficient the compiler selects v_fmac_f64, whose addend must sit in the destination VGPRs, and
+// pays two v_mov_b32 per step to put it there (measured: 28 v_mov for 18 FMAs in the 14-term tier);
+// VOP3 v_fma_f64 takes the coefficient straight from SGPRs (scalar-loaded record field or s_mov'd
+// literal), which moves that work from the VALU to the scalar unit.
+__device__ __forceinline__ double fma_s(double a, double b, double c_uniform) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
+
 // 1/d to full double precision without the IEEE division sequence (no scaling/fixup needed:
 // callers pass finite, normal, non-zero values; NaN/inf/0 propagate harmlessly).
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -158,7 +169,7 @@ __device__ __forceinline__ double wing_tau(double x, const double* __restrict__ 
     const double s = fast_rcp1(x * x);
     double acc = K[M - 1];
 #pragma unroll
-    for (int m = M - 2; m >= 0; --m) acc = __builtin_fma(acc, s, K[m]);
+    for (int m = M - 2; m >= 0; --m) acc = fma_s(acc, s, K[m]);
     return acc * s;
 }
 
@@ -167,28 +178,28 @@ __device__ __forceinline__ double wing_tau(double x, const double* __restrict__ 
 __device__ __forceinline__ double sinc_small(double t) {   // sin(t)/t
     const double t2 = t * t;
     double p = -8.2206352466243297e-18;               // -1/19!
-    p = __builtin_fma(p, t2, 2.8114572543455208e-15);   //  1/17!
-    p = __builtin_fma(p, t2, -7.6471637318198165e-13);  // -1/15!
-    p = __builtin_fma(p, t2, 1.6059043836821615e-10);   //  1/13!
-    p = __builtin_fma(p, t2, -2.5052108385441719e-08);  // -1/11!
-    p = __builtin_fma(p, t2, 2.7557319223985891e-06);   //  1/9!
-    p = __builtin_fma(p, t2, -1.9841269841269841e-04);  // -1/7!
-    p = __builtin_fma(p, t2, 8.3333333333333333e-03);   //  1/5!
-    p = __builtin_fma(p, t2, -1.6666666666666667e-01);  // -1/3!
+    p = __builtin_fma(p,t2, 2.8114572543455208e-15);   //  1/17!
+    p = __builtin_fma(p,t2, -7.6471637318198165e-13);  // -1/15!
+    p = __builtin_fma(p,t2, 1.6059043836821615e-10);   //  1/13!
+    p = __builtin_fma(p,t2, -2.5052108385441719e-08);  // -1/11!
+    p = __builtin_fma(p,t2, 2.7557319223985891e-06);   //  1/9!
+    p = __builtin_fma(p,t2, -1.9841269841269841e-04);  // -1/7!
+    p = __builtin_fma(p,t2, 8.3333333333333333e-03);   //  1/5!
+    p = __builtin_fma(p,t2, -1.6666666666666667e-01);  // -1/3!
     return __builtin_fma(p, t2, 1.0);
 }
 __device__ __forceinline__ double cos_small(double t) {
     const double t2 = t * t;
     double p = 8.8967791632530450e-22;                 //  1/22!
-    p = __builtin_fma(p, t2, -4.1103176233121649e-19);  // -1/20!
-    p = __builtin_fma(p, t2, 1.5619206968586226e-16);   //  1/18!
-    p = __builtin_fma(p, t2, -4.7794773323873853e-14);  // -1/16!
-    p = __builtin_fma(p, t2, 1.1470745597729725e-11);   //  1/14!
-    p = __builtin_fma(p, t2, -2.0876756987868099e-09);  // -1/12!
-    p = __builtin_fma(p, t2, 2.7557319223985891e-07);   //  1/10!
-    p = __builtin_fma(p, t2, -2.4801587301587302e-05);  // -1/8!
-    p = __builtin_fma(p, t2, 1.3888888888888889e-03);   //  1/6!
-    p = __builtin_fma(p, t2, -4.1666666666666667e-02);  // -1/4!
+    p = __builtin_fma(p,t2, -4.1103176233121649e-19);  // -1/20!
+    p = __builtin_fma(p,t2, 1.5619206968586226e-16);   //  1/18!
+    p = __builtin_fma(p,t2, -4.7794773323873853e-14);  // -1/16!
+    p = __builtin_fma(p,t2, 1.1470745597729725e-11);   //  1/14!
+    p = __builtin_fma(p,t2, -2.0876756987868099e-09);  // -1/12!
+    p = __builtin_fma(p,t2, 2.7557319223985891e-07);   //  1/10!
+    p = __builtin_fma(p,t2, -2.4801587301587302e-05);  // -1/8!
+    p = __builtin_fma(p,t2, 1.3888888888888889e-03);   //  1/6!
+    p = __builtin_fma(p,t2, -4.1666666666666667e-02);  // -1/4!
     p = __builtin_fma(p, t2, 0.5);
     return __builtin_fma(-p, t2, 1.0);
 }
@@ -197,8 +208,8 @@ __device__ __forceinline__ double cos_small(double t) {
 __device__ __forceinline__ double cos_tiny(double t) {
     const double t2 = t * t;
     double p = 2.4801587301587302e-05;                   //  1/8!
-    p = __builtin_fma(p, t2, -1.3888888888888889e-03);   // -1/6!
-    p = __builtin_fma(p, t2, 4.1666666666666667e-02);    //  1/4!
+    p = __builtin_fma(p,t2, -1.3888888888888889e-03);   // -1/6!
+    p = __builtin_fma(p,t2, 4.1666666666666667e-02);    //  1/4!
     p = __builtin_fma(p, t2, -0.5);
     return __builtin_fma(p, t2, 1.0);
 }

@@ -382,6 +382,7 @@ constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span =
 #ifndef VP_RB
 #define VP_RB 3     // measured: RB=3 (91 VGPRs, 5 waves/SIMD) beats RB=2 (79, 6) and RB=4 (109, 4) by 3-5 %
 #endif
+constexpr int FL_PAD = 8;         // LDS doubles after a tile's flux that the zero-padded taps may read
 constexpr int RB = VP_RB;         // 64-pixel chunks per wave pass (register blocking / ILP)
 
 // s * Horner_M(K, s) for RB independent chunks with the same M; K wave-uniform (SGPR operands).
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                                                             double* __restrict__ out, int out_stride,
                                                             int out_offset, FinalizeArgs F,
                                                             const int* __restrict__ genflag) {
-    // LDS: fl[span] tau -> flux | red[4] | Dawson table | LSF taps | per-chunk "line core" masks
+    // LDS: fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | LSF taps (zero-padded to 8k) | exp table | per-chunk "line core" masks
     extern __shared__ double fl[];
     // walkers are the fast grid dimension and the (short) last tile comes last, so the tail of the
     // launch is filled with the cheapest workgroups
@@ -443,9 +444,10 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     const double* __restrict__ lcw = lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int TILE_THREADS = blockDim.x, nwaves = blockDim.x >> 6;
-    double* __restrict__ daw = fl + I.span + 4;        // Dawson table for the line cores (16-B aligned)
+    double* __restrict__ daw = fl + I.span + FL_PAD + 4;   // Dawson table for the line cores (16-B aligned)
     double* __restrict__ ktap = daw + DAW_LDS_DOUBLES; // LSF taps, read back as LDS broadcasts
-    double* __restrict__ etab = ktap + I.K;            // 2^(j/64) for the table-driven exp
+    const int Kp = (I.K + 7) & ~7;                     // taps padded with zeros to whole groups of 8
+    double* __restrict__ etab = ktap + Kp;             // 2^(j/64) for the table-driven exp
     unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(etab + EXP_LDS_DOUBLES);
     const int nwords = (I.L + 63) >> 6;                // 64 lines per mask word
     const int nchunks = (n_eval + 63) >> 6;
@@ -464,8 +466,9 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     }
     if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
     if (GENERIC ? (gen == 0) : (gen != 0)) return;   // the other launch owns this walker
-    if ((int)threadIdx.x < I.K) ktap[threadIdx.x] = tap_pre;
-    for (int j = threadIdx.x + TILE_THREADS; j < I.K; j += TILE_THREADS) ktap[j] = I.kflip[j];
+    if ((int)threadIdx.x < Kp) ktap[threadIdx.x] = (int)threadIdx.x < I.K ? tap_pre : 0.0;
+    for (int j = threadIdx.x + TILE_THREADS; j < Kp; j += TILE_THREADS) ktap[j] = j < I.K ? I.kflip[j] : 0.0;
+    if (threadIdx.x < FL_PAD) fl[n_eval + threadIdx.x] = 0.0;   // what the zero taps multiply must be finite
     if (threadIdx.x < EXP_LDS_DOUBLES) etab[threadIdx.x] = exp_pre;
 
 #ifdef VP_STAMP
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #if defined(VP_ABLATE) && (VP_ABLATE == 2 || VP_ABLATE == 7)
             const int kn = 1;
 #else
-            const int kn = I.K;
+            const int kn = Kp;                                    // zero taps: fma(0, finite, m) == m exactly
 #endif
             const double* fb[RB];
 #pragma unroll
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #endif
     if (OUT == 0) {
         acc = wave_sum(acc);
-        double* red = fl + I.span;
+        double* red = fl + I.span + FL_PAD;
         if (lane == 0) red[wid] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
