@@ -128,3 +128,125 @@ class DeviceStretchSampler:
     def get_chain(self, discard: int = 0, flat: bool = False):
         c = self.chain[discard:]
         return c.reshape(-1, self.ndim) if flat else c
+
+
+class EnsembleSliceSampler:
+    """Ensemble slice sampling with the differential move (Karamanis, Beutler & Peacock 2021) -- the
+    algorithm of ``zeus.EnsembleSampler``, which the reference offers as ``sampler='zeus'``
+    (vfit_mcmc.py:425-440) and which is absent from this image.  Fully batched: every stepping-out
+    or shrinking round is ONE lnprob call over the walkers still active in it, so the batches are
+    ragged (W/2, then fewer and fewer rows) -- the call shape SURVEY 3.1 describes for zeus.
+
+    Per iteration the ensemble is split at random into two halves; each walker of the active half
+    slices along eta = mu * 2.38/sqrt(2 D) * (X_l - X_m), l != m drawn from the other half.  ``mu``
+    is tuned during ``tune_steps`` iterations towards equal numbers of expansions and contractions.
+    ``lnprob`` maps (n, D) -> (n,)."""
+
+    def __init__(self, nwalkers: int, ndim: int, lnprob: Callable, mu: float = 1.0, maxsteps: int = 10000,
+                 tune: bool = True, tolerance: float = 0.05, patience: int = 5, seed: Optional[int] = None):
+        if nwalkers % 2 or nwalkers < 2 * ndim:
+            raise ValueError("nwalkers must be even and at least 2*ndim (as zeus requires)")
+        self.nwalkers, self.ndim, self.lnprob = nwalkers, ndim, lnprob
+        self.mu, self.maxsteps, self.tune = float(mu), int(maxsteps), bool(tune)
+        self.tolerance, self.patience, self._good = float(tolerance), int(patience), 0
+        self.rng = np.random.default_rng(seed)
+        self.chain = None
+        self.lnprobability = None
+        self.nsteps = 0
+        self.n_lnprob_calls = 0
+        self.n_lnprob_evals = 0
+        self.batch_sizes = []                       # rows per lnprob call (diagnostic: the ragged shapes)
+        self.mu_history = []
+
+    def _eval(self, pos):
+        lp = np.asarray(self.lnprob(pos), dtype=np.float64)
+        self.n_lnprob_calls += 1
+        self.n_lnprob_evals += len(pos)
+        self.batch_sizes.append(len(pos))
+        if np.any(np.isnan(lp)):
+            raise ValueError("Probability function returned NaN")
+        return lp
+
+    def run_mcmc(self, p0, nsteps: int, lnprob0=None):
+        pos = np.array(p0, dtype=np.float64)
+        if pos.shape != (self.nwalkers, self.ndim):
+            raise ValueError(f"initial state must have shape ({self.nwalkers}, {self.ndim})")
+        lp = self._eval(pos) if lnprob0 is None else np.array(lnprob0, dtype=np.float64)
+        if not np.all(np.isfinite(lp)):
+            raise ValueError("initial walkers must have finite lnprob")
+        chain = np.empty((nsteps, self.nwalkers, self.ndim))
+        lnps = np.empty((nsteps, self.nwalkers))
+        half = self.nwalkers // 2
+        gamma0 = 2.38 / np.sqrt(2.0 * self.ndim)
+        rng = self.rng
+        for it in range(nsteps):
+            perm = rng.permutation(self.nwalkers)
+            nexp = ncon = 0
+            for S, C in ((perm[:half], perm[half:]), (perm[half:], perm[:half])):
+                n = S.size
+                # two distinct partners from the complementary half
+                l = rng.integers(0, C.size, n)
+                m = (l + 1 + rng.integers(0, C.size - 1, n)) % C.size
+                eta = self.mu * gamma0 * (pos[C[l]] - pos[C[m]])
+                X = pos[S]
+                Z0 = lp[S] - rng.exponential(size=n)
+                L = -rng.random(n)
+                R = L + 1.0
+                J = np.floor(self.maxsteps * rng.random(n)).astype(np.int64)
+                K = (self.maxsteps - 1) - J
+                # stepping out, left then right: one batch per round over the walkers still expanding
+                for edge, budget, sign in ((L, J, -1.0), (R, K, 1.0)):
+                    act = np.arange(n)
+                    while act.size:
+                        act = act[budget[act] > 0]
+                        if not act.size:
+                            break
+                        out = self._eval(X[act] + edge[act, None] * eta[act]) > Z0[act]
+                        act = act[out]
+                        edge[act] += sign
+                        budget[act] -= 1
+                        nexp += act.size
+                # shrinking
+                Xn, lpn = X.copy(), lp[S].copy()
+                act = np.arange(n)
+                while act.size:
+                    Wd = L[act] + rng.random(act.size) * (R[act] - L[act])
+                    prop = X[act] + Wd[:, None] * eta[act]
+                    lpp = self._eval(prop)
+                    ok = lpp > Z0[act]
+                    Xn[act[ok]], lpn[act[ok]] = prop[ok], lpp[ok]
+                    rej = act[~ok]
+                    wr = Wd[~ok]
+                    L[rej] = np.where(wr < 0, wr, L[rej])
+                    R[rej] = np.where(wr < 0, R[rej], wr)
+                    ncon += rej.size
+                    act = rej
+                pos[S], lp[S] = Xn, lpn
+            if self.tune:
+                ratio = 2.0 * max(1, nexp) / (max(1, nexp) + ncon)
+                self.mu *= ratio
+                self._good = self._good + 1 if abs(ratio - 1.0) < self.tolerance else 0
+                if self._good >= self.patience:
+                    self.tune = False
+            self.mu_history.append(self.mu)
+            chain[it], lnps[it] = pos, lp
+        self.chain = chain if self.chain is None else np.concatenate([self.chain, chain])
+        self.lnprobability = lnps if self.lnprobability is None else np.concatenate([self.lnprobability, lnps])
+        self.nsteps += nsteps
+        return pos, lp
+
+    def get_chain(self, discard: int = 0, flat: bool = False):
+        c = self.chain[discard:]
+        return c.reshape(-1, self.ndim) if flat else c
+
+
+def gelman_rubin(chain) -> np.ndarray:
+    """Potential scale reduction R-hat per parameter for a (nsteps, nwalkers, D) chain, walkers as the
+    parallel chains -- the diagnostic the reference prints for zeus runs (vfit_mcmc.py:633-640)."""
+    c = np.asarray(chain, dtype=np.float64)
+    n, m = c.shape[0], c.shape[1]
+    means = c.mean(axis=0)                                  # (m, D)
+    W = c.var(axis=0, ddof=1).mean(axis=0)
+    B = n * means.var(axis=0, ddof=1)
+    var = (n - 1) / n * W + B / n
+    return np.sqrt(var / W)

@@ -239,7 +239,9 @@ class vfit:
         initialisation (:442-466) and ``no_of_steps`` ensemble steps with ONE batched GPU lnprob
         call per half-ensemble.  ``sampler``: 'emcee' (``vectorize=True``), 'host'
         (``rbvfit_amd.sampler.StretchMoveSampler``), 'device' (``DeviceStretchSampler``: the whole
-        loop in HBM) or 'auto' (emcee when installed, else 'host').  ``use_pool`` must stay False: a HIP
+        loop in HBM), 'zeus' / 'host-slice' (ensemble slice sampling: zeus itself or
+        ``EnsembleSliceSampler``, ragged batches) or 'auto' (the constructor's ``sampler=`` choice:
+        emcee/zeus when installed, else the matching host driver).  ``use_pool`` must stay False: a HIP
         context cannot be shared with forked workers, and batching replaces the Pool."""
         if use_pool:
             raise ValueError("use_pool=True is not supported: the batched GPU lnprob replaces the fork Pool")
@@ -249,15 +251,27 @@ class vfit:
         rng = np.random.default_rng(seed)
         guesses = initialize_walkers(self.theta, self.lb, self.ub, self.no_of_Chain, self.perturbation,
                                      self.lnprob, rng)
-        if sampler not in ("auto", "emcee", "host", "device"):
-            raise ValueError("sampler must be 'auto', 'emcee', 'host' or 'device'")
-        if sampler == "auto":
+        if sampler not in ("auto", "emcee", "zeus", "host", "host-slice", "device"):
+            raise ValueError("sampler must be 'auto', 'emcee', 'zeus', 'host', 'host-slice' or 'device'")
+        if sampler == "auto":                          # the constructor's sampler= choice, as in the reference
             try:
-                import emcee  # noqa: F401
-                sampler = "emcee"
+                if self.sampler_name == "zeus":
+                    import zeus  # noqa: F401
+                    sampler = "zeus"
+                else:
+                    import emcee  # noqa: F401
+                    sampler = "emcee"
             except ImportError:
-                sampler = "host"
-        if sampler == "emcee":
+                sampler = "host-slice" if self.sampler_name == "zeus" else "host"
+        if sampler == "zeus":                          # vfit_mcmc.py:425-440
+            import zeus
+            sampler = zeus.EnsembleSampler(self.no_of_Chain, self.ndim, self.lnprob, vectorize=True, verbose=verbose)
+            sampler.run_mcmc(guesses, self.no_of_steps)
+        elif sampler == "host-slice":
+            from .sampler import EnsembleSliceSampler
+            sampler = EnsembleSliceSampler(self.no_of_Chain, self.ndim, self.lnprob, seed=seed)
+            sampler.run_mcmc(guesses, self.no_of_steps)
+        elif sampler == "emcee":
             import emcee
             sampler = emcee.EnsembleSampler(self.no_of_Chain, self.ndim, self.lnprob, vectorize=True)
             sampler.run_mcmc(guesses, self.no_of_steps, progress=verbose)

@@ -100,3 +100,35 @@ def test_vfit_runmcmc_on_the_device():
             fit.runmcmc(sampler="nope")
     finally:
         fit.close()
+
+
+def test_slice_sampler_ragged_batches_on_the_engine():
+    """sampler='zeus' in the reference (vfit_mcmc.py:425-440): ensemble slice sampling calls lnprob
+    with shrinking, ragged batches; every stored lnprob must be the engine's value for the stored
+    position and the distribution must agree with the stretch move's."""
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    from rbvfit_amd.sampler import EnsembleSliceSampler
+    from rbvfit_amd.vfit import vfit
+    wl = _workload()
+    eng, p0 = wl.engine, wl.thetas
+    sl = EnsembleSliceSampler(48, 6, eng.lnprob, seed=3)
+    sl.run_mcmc(p0, 600)
+    assert min(sl.batch_sizes) == 1 and max(sl.batch_sizes[1:]) == 24 and len(set(sl.batch_sizes)) > 10   # [0]: the initial 48
+    np.testing.assert_array_equal(sl.lnprobability[-1], eng.lnprob(sl.chain[-1]))
+    dev = eng.stretch_run(p0, 4000, seed=1)[2][1000:].reshape(-1, 6)
+    s = sl.get_chain(discard=200, flat=True)
+    sd = dev.std(axis=0)
+    assert np.all(np.abs(s.mean(axis=0) - dev.mean(axis=0)) < 0.5 * sd)
+    assert np.all(s.std(axis=0) / sd > 0.6) and np.all(s.std(axis=0) / sd < 1.6)
+    assert np.all(s >= wl.lb) and np.all(s <= wl.ub)
+    # the reference's constructor switch: sampler='zeus' -> slice sampling (zeus itself when installed)
+    wave, flux, err = wl.spectra[0]
+    cfg = FitConfiguration(); cfg.add_system(0.348, "MgII", [2796.35, 2803.53], 2)
+    fit = vfit({"G": {"model": VoigtModel(cfg, FWHM="6.5"), "wave": wave, "flux": flux, "error": err}},
+               wl.theta_true, wl.lb, wl.ub, no_of_Chain=24, no_of_steps=30, sampler="zeus")
+    try:
+        smp = fit.runmcmc(seed=2)
+        assert type(smp).__name__ in ("EnsembleSliceSampler", "EnsembleSampler")
+        assert fit.samples.shape == (24 * 24, 6)
+    finally:
+        fit.close()

@@ -196,3 +196,54 @@ def test_philox4x32_known_answers_and_python_restatement():
         ctr = [int(v) for v in rng.integers(0, 2 ** 32, 4)]
         key = [int(v) for v in rng.integers(0, 2 ** 32, 2)]
         assert _philox_lib(ctr, key) == _philox_py(ctr, key)
+
+
+# ---- host ensemble drivers on an analytic posterior (no GPU needed) ----------------------------------
+def _gauss3():
+    cov = np.array([[1.0, 0.6, -0.3], [0.6, 2.0, 0.4], [-0.3, 0.4, 0.5]])
+    mean = np.array([1.0, -2.0, 0.5])
+    icov = np.linalg.inv(cov)
+
+    def lnprob(x):
+        d = np.atleast_2d(x) - mean
+        out = -0.5 * np.einsum("ij,jk,ik->i", d, icov, d)
+        out[np.any(np.abs(d) > 50, axis=1)] = -np.inf            # a box prior, as vfit has
+        return out
+    return mean, cov, lnprob
+
+
+@pytest.mark.parametrize("kind", ["stretch", "slice"])
+def test_host_samplers_recover_a_correlated_gaussian(kind):
+    from rbvfit_amd.sampler import EnsembleSliceSampler, StretchMoveSampler, gelman_rubin
+    mean, cov, lnprob = _gauss3()
+    rng = np.random.default_rng(0)
+    p0 = mean + 0.1 * rng.standard_normal((24, 3))
+    if kind == "stretch":
+        s = StretchMoveSampler(24, 3, lnprob, seed=1)
+        s.run_mcmc(p0, 3000)
+        burn = 500
+    else:
+        s = EnsembleSliceSampler(24, 3, lnprob, seed=1)
+        s.run_mcmc(p0, 800)
+        burn = 200
+        assert min(s.batch_sizes) < 12 and max(s.batch_sizes) == 24          # ragged batches: 12, then fewer
+        assert 0.1 < s.mu < 20                                               # tuned scale stays sane
+        assert 4 < s.n_lnprob_evals / (800 * 24) < 15                        # ~5-10 evaluations per walker-step
+    flat = s.get_chain(discard=burn, flat=True)
+    sd = np.sqrt(np.diag(cov))
+    assert np.all(np.abs(flat.mean(axis=0) - mean) < 0.15 * sd)
+    assert np.all(np.abs(np.cov(flat.T) - cov) < 0.2 * np.outer(sd, sd))
+    assert np.all(gelman_rubin(s.get_chain(discard=burn)) < 1.1)
+    np.testing.assert_allclose(s.lnprobability[-1], lnprob(s.chain[-1]), rtol=1e-12, atol=1e-12)
+
+
+def test_slice_sampler_rejects_nan_and_bad_shapes():
+    from rbvfit_amd.sampler import EnsembleSliceSampler
+    with pytest.raises(ValueError):
+        EnsembleSliceSampler(5, 3, lambda x: np.zeros(len(x)))
+    s = EnsembleSliceSampler(8, 2, lambda x: np.full(len(x), np.nan), seed=0)
+    with pytest.raises(ValueError, match="NaN"):
+        s.run_mcmc(np.zeros((8, 2)), 1)
+    s = EnsembleSliceSampler(8, 2, lambda x: np.full(len(x), -np.inf), seed=0)
+    with pytest.raises(ValueError, match="finite"):
+        s.run_mcmc(np.zeros((8, 2)), 1)
