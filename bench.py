@@ -333,6 +333,7 @@ def main():
     if use_dist:
         if rank == 0 and gathered is not None:
             assert torch.equal(gathered[:W], d_out), "all-gathered lnprob differs from the local block"
+        dist.barrier()                       # rank 0's extra legs are done: leave together
         dist.destroy_process_group()
 
 
