@@ -309,3 +309,48 @@ def test_long_tabulated_kernels(K):
     np.testing.assert_allclose(got, vo.lnprob_batch(th, lb, ub, [inst]), rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     for i in range(2):
         np.testing.assert_allclose(fl[i], vo.model_flux(od, th[i], wave), rtol=0, atol=FLUX_ATOL)
+
+
+def test_integration_md_binding_stub_runs_as_written():
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer would add to rbvfit; execute that
+    very text against the in-tree library with a duck-typed fitter (the attributes the stub reads:
+    vfit.lb/ub/instrument_data, the bound model_flux's __self__.data = CompiledModelData fields,
+    kernel.array) and compare with the golden lnprob."""
+    import os
+    import re
+    import types
+    from rbvfit_amd import _lib
+    z = load_golden("c0_mgii")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# src/rbvfit/_amd_backend\.py.*?)```", md, flags=re.S).group(1)
+    block = block.replace('C.CDLL("librbvfit_amd.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+
+    class Gaussian1DKernel:                                   # only the class name and .array are read
+        def __init__(self, array):
+            self.array = array
+
+    g = lambda k: z[f"G__{k}"]
+    data = types.SimpleNamespace(atomic_lambda0=g("lambda0"), atomic_gamma=g("gamma").astype(np.float32),
+                                 atomic_f=g("f").astype(np.float32), z_factors=g("zfac"), N_indices=g("N_idx"),
+                                 b_indices=g("b_idx"), v_indices=g("v_idx"), kernel=Gaussian1DKernel(g("taps")),
+                                 n_lines=len(g("lambda0")), voigt_method="wofz")
+
+    class Compiled:
+        def __init__(self, d):
+            self.data = d
+
+        def model_flux(self, theta, wave):                   # never called: the engine replaces it
+            raise AssertionError
+
+    fitter = types.SimpleNamespace(lb=z["lb"], ub=z["ub"], instrument_data={
+        "G": {"model": Compiled(data).model_flux, "wave": g("wave"), "flux": g("flux"),
+              "inv_sigma2": g("inv_sigma2"), "log_inv_sigma2": g("log_inv_sigma2")}})
+    post = ns["AmdPosterior"](fitter)
+    got = post(z["thetas"])
+    fin = np.isfinite(z["lnprob"])
+    np.testing.assert_allclose(got[fin], z["lnprob"][fin], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    assert np.array_equal(np.isneginf(got), np.isneginf(z["lnprob"]))
+    assert isinstance(post(z["thetas"][0]), float)
