@@ -623,20 +623,35 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     if (have_lnprob) HIP_TRY(c, hipMemcpyAsync(d_lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, s));
     else if ((rc = enqueue_lnprob(c, W, d_pos, d_lp, s))) return rc;
     const int thr = 64;
+    const bool fuse = W <= 1024 && !getenv("RBVFIT_AMD_NO_FUSED_ACCEPT");   // accept + next proposal in one launch
+    const int wthr = ((W + 63) / 64) * 64;
+    bool have_prop = false;                                   // is the proposal of the coming pass already enqueued?
     for (int done = 0; done < nsteps;) {
         const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
         for (int it = 0; it < n; ++it) {
             const uint64_t step = step0 + (uint64_t)(done + it);
             for (int h = 0; h < 2; ++h) {
                 const int s0 = h ? half : 0, c0 = h ? 0 : half;
-                hipLaunchKernelGGL(vp::stretch_propose_kernel, dim3((half + thr - 1) / thr), dim3(thr), 0, s, d_pos, D, s0, half,
-                                   c0, half, a, seed, step, h, d_prop, d_zz);
+                if (!have_prop)
+                    hipLaunchKernelGGL(vp::stretch_propose_kernel, dim3((half + thr - 1) / thr), dim3(thr), 0, s, d_pos, D, s0,
+                                       half, c0, half, a, seed, step, h, d_prop, d_zz);
                 if ((rc = enqueue_lnprob(c, half, d_prop, d_lpnew, s))) return rc;
                 const bool store = chain && h == 1;
-                hipLaunchKernelGGL(vp::stretch_accept_kernel, dim3((W + thr - 1) / thr), dim3(thr), 0, s, d_pos, d_lp, d_prop,
-                                   d_lpnew, d_zz, W, D, s0, half, seed, step, h, d_nacc, d_nan,
-                                   store ? d_chain + (size_t)it * W * D : (double*)nullptr,
-                                   store ? d_chain + chunk * (size_t)W * D + (size_t)it * W : (double*)nullptr);
+                double* cp = store ? d_chain + (size_t)it * W * D : (double*)nullptr;
+                double* cl = store ? d_chain + chunk * (size_t)W * D + (size_t)it * W : (double*)nullptr;
+                const bool last = (h == 1) && (done + it + 1 == nsteps);
+                if (fuse && !last) {
+                    vp::NextProposal nx;
+                    nx.half = 1 - h; nx.s0 = nx.half ? half : 0; nx.c0 = nx.half ? 0 : half; nx.nS = half; nx.nC = half;
+                    nx.step = h ? step + 1 : step;
+                    hipLaunchKernelGGL(vp::stretch_accept_propose_kernel, dim3(1), dim3(wthr), 0, s, d_pos, d_lp, d_prop,
+                                       d_lpnew, d_zz, W, D, s0, half, seed, step, h, d_nacc, d_nan, cp, cl, a, nx);
+                    have_prop = true;
+                } else {
+                    hipLaunchKernelGGL(vp::stretch_accept_kernel, dim3((W + thr - 1) / thr), dim3(thr), 0, s, d_pos, d_lp, d_prop,
+                                       d_lpnew, d_zz, W, D, s0, half, seed, step, h, d_nacc, d_nan, cp, cl);
+                    have_prop = false;
+                }
             }
         }
         HIP_TRY(c, hipGetLastError());

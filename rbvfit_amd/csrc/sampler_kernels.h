@@ -43,10 +43,9 @@ __device__ inline Philox4 draw(uint64_t seed, uint64_t step, int half, int walke
 
 // Proposal for the nS walkers of half S (rows [s0, s0+nS)) against the complementary rows [c0, c0+nC):
 //   z ~ g(z) ∝ 1/sqrt(z) on [1/a, a]:  z = ((a-1) u + 1)^2 / a;   Y = X_j + z (X_k - X_j)
-__global__ void stretch_propose_kernel(const double* __restrict__ pos, int D, int s0, int nS, int c0, int nC, double a,
-                                       uint64_t seed, uint64_t step, int half, double* __restrict__ prop,
+__device__ inline void stretch_propose(int k, const double* __restrict__ pos, int D, int s0, int nS, int c0, int nC,
+                                       double a, uint64_t seed, uint64_t step, int half, double* __restrict__ prop,
                                        double* __restrict__ zz) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nS) return;
     const Philox4 r = draw(seed, step, half, s0 + k, 0u);
     const double u1 = u01(r.v[0], r.v[1]), u2 = u01(r.v[2], r.v[3]);
@@ -60,16 +59,20 @@ __global__ void stretch_propose_kernel(const double* __restrict__ pos, int D, in
     for (int d = 0; d < D; ++d) y[d] = c[d] - (c[d] - x[d]) * z;
     zz[k] = z;
 }
+__global__ void stretch_propose_kernel(const double* __restrict__ pos, int D, int s0, int nS, int c0, int nC, double a,
+                                       uint64_t seed, uint64_t step, int half, double* __restrict__ prop,
+                                       double* __restrict__ zz) {
+    stretch_propose(blockIdx.x * blockDim.x + threadIdx.x, pos, D, s0, nS, c0, nC, a, seed, step, half, prop, zz);
+}
 
 // Accept/reject for half S and, when chain_pos != nullptr, storage of the whole ensemble's state
 // (row `w` is handled by thread w; rows outside S are only stored).
 //   ln q = (D-1) ln z + lnprob(Y) - lnprob(X);  accept when ln u < ln q.   NaN lnprob(Y) -> flag (emcee raises).
-__global__ void stretch_accept_kernel(double* __restrict__ pos, double* __restrict__ lp, const double* __restrict__ prop,
-                                      const double* __restrict__ lp_new, const double* __restrict__ zz, int W, int D,
-                                      int s0, int nS, uint64_t seed, uint64_t step, int half,
-                                      long long* __restrict__ nacc, int* __restrict__ nanflag,
+__device__ inline void stretch_accept(int w, double* __restrict__ pos, double* __restrict__ lp,
+                                      const double* __restrict__ prop, const double* __restrict__ lp_new,
+                                      const double* __restrict__ zz, int W, int D, int s0, int nS, uint64_t seed,
+                                      uint64_t step, int half, long long* __restrict__ nacc, int* __restrict__ nanflag,
                                       double* __restrict__ chain_pos, double* __restrict__ chain_lp) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= W) return;
     double* __restrict__ x = pos + (size_t)w * D;
     const int k = w - s0;
@@ -94,6 +97,29 @@ __global__ void stretch_accept_kernel(double* __restrict__ pos, double* __restri
         for (int d = 0; d < D; ++d) o[d] = x[d];
         chain_lp[w] = lp[w];
     }
+}
+__global__ void stretch_accept_kernel(double* __restrict__ pos, double* __restrict__ lp, const double* __restrict__ prop,
+                                      const double* __restrict__ lp_new, const double* __restrict__ zz, int W, int D,
+                                      int s0, int nS, uint64_t seed, uint64_t step, int half,
+                                      long long* __restrict__ nacc, int* __restrict__ nanflag,
+                                      double* __restrict__ chain_pos, double* __restrict__ chain_lp) {
+    stretch_accept(blockIdx.x * blockDim.x + threadIdx.x, pos, lp, prop, lp_new, zz, W, D, s0, nS, seed, step, half, nacc,
+                   nanflag, chain_pos, chain_lp);
+}
+
+// Accept/reject of one half followed by the proposal for the other half, in ONE single-workgroup launch
+// (W <= 1024): the barrier orders the accepted positions before the proposals that read them.  Saves
+// a launch per half-ensemble pass (each of these tiny kernels is launch latency and nothing else).
+struct NextProposal { int s0, nS, c0, nC, half; uint64_t step; };
+__global__ __launch_bounds__(1024) void stretch_accept_propose_kernel(
+    double* __restrict__ pos, double* __restrict__ lp, double* __restrict__ prop, double* __restrict__ lp_new,
+    double* __restrict__ zz, int W, int D, int s0, int nS, uint64_t seed, uint64_t step, int half,
+    long long* __restrict__ nacc, int* __restrict__ nanflag, double* __restrict__ chain_pos,
+    double* __restrict__ chain_lp, double a, NextProposal nx) {
+    stretch_accept(threadIdx.x, pos, lp, prop, lp_new, zz, W, D, s0, nS, seed, step, half, nacc, nanflag, chain_pos,
+                   chain_lp);
+    __syncthreads();             // all reads of prop/zz and all writes of pos by this launch's accept are done
+    stretch_propose(threadIdx.x, pos, D, nx.s0, nx.nS, nx.c0, nx.nC, a, seed, nx.step, nx.half, prop, zz);
 }
 
 }  // namespace vp

@@ -42,6 +42,13 @@ def test_runs_are_reproducible_and_splittable():
     np.testing.assert_array_equal(h2[4], a[4])
     c = eng.stretch_run(p0, 20, seed=12)
     assert not np.array_equal(c[2], a[2])
+    import os
+    os.environ["RBVFIT_AMD_NO_FUSED_ACCEPT"] = "1"            # separate accept / propose launches: same draws
+    try:
+        u = eng.stretch_run(p0, 20, seed=11)
+    finally:
+        del os.environ["RBVFIT_AMD_NO_FUSED_ACCEPT"]
+    np.testing.assert_array_equal(u[2], a[2]); np.testing.assert_array_equal(u[4], a[4])
     nochain = eng.stretch_run(p0, 20, seed=11, store_chain=False)
     assert nochain[2] is None
     np.testing.assert_array_equal(nochain[0], a[0])
