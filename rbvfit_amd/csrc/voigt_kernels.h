@@ -441,7 +441,11 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     const int nout = p1 - p0;
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
+#if defined(VP_ABLATE) && VP_ABLATE == 8
+    const double* __restrict__ lcw = lc;                // timing experiment: every walker reads walker 0's records
+#else
     const double* __restrict__ lcw = lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE;
+#endif
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int TILE_THREADS = blockDim.x, nwaves = blockDim.x >> 6;
     double* __restrict__ daw = fl + I.span + FL_PAD + 4;   // Dawson table for the line cores (16-B aligned)
