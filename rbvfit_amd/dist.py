@@ -171,21 +171,25 @@ class PipelinedGather:
 class IslandEnsemble:
     """G independent stretch-move ensembles, one per rank, targeting the same posterior.
 
-    Each rank runs ``StretchMoveSampler`` over its own ``nwalkers_local`` walkers (seed offset by the
-    rank) against its own engine, so an MCMC step needs no exchange at all; ``gather_chain`` then
+    Each rank runs ``StretchMoveSampler`` (or, with ``engine=``, the device-resident
+    ``DeviceStretchSampler``) over its own ``nwalkers_local`` walkers (seed offset by the rank)
+    against its own engine, so an MCMC step needs no exchange at all; ``gather_chain`` then
     collects the per-rank chains with ONE all-gather (one large collective instead of one per
     step).  Statistically this is the usual "many short independent ensembles" scheme: the pooled
     samples are draws from the same posterior, and between-island agreement is a convergence check
     (``island_means``)."""
 
-    def __init__(self, local_lnprob: Callable, nwalkers_local: int, ndim: int, seed: int = 0, group=None,
-                 device: Optional[str] = None):
+    def __init__(self, local_lnprob: Optional[Callable], nwalkers_local: int, ndim: int, seed: int = 0, group=None,
+                 device: Optional[str] = None, engine=None):
         import torch.distributed as dist
-        from .sampler import StretchMoveSampler
+        from .sampler import DeviceStretchSampler, StretchMoveSampler
         self._dist, self.group, self.device = dist, group, device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.sampler = StretchMoveSampler(nwalkers_local, ndim, local_lnprob, seed=seed * 1000003 + self.rank)
+        if engine is not None:           # the rank's whole walker loop on its GPU (vp_stretch_run)
+            self.sampler = DeviceStretchSampler(nwalkers_local, ndim, engine, seed=seed * 1000003 + self.rank)
+        else:
+            self.sampler = StretchMoveSampler(nwalkers_local, ndim, local_lnprob, seed=seed * 1000003 + self.rank)
 
     def run_mcmc(self, p0_local, nsteps: int):
         return self.sampler.run_mcmc(p0_local, nsteps)

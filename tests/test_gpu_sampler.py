@@ -139,3 +139,15 @@ def test_slice_sampler_ragged_batches_on_the_engine():
         assert fit.samples.shape == (24 * 24, 6)
     finally:
         fit.close()
+
+
+def test_island_ensemble_with_the_device_sampler():
+    """One island per rank, each running vp_stretch_run on its own GPU (here: a single rank)."""
+    from rbvfit_amd.dist import IslandEnsemble
+    wl = _workload(W=24, pixels=256)
+    isl = IslandEnsemble(None, 24, 6, seed=5, engine=wl.engine)
+    isl.run_mcmc(wl.thetas, 30)
+    chain, lnp = isl.gather_chain(discard=10)
+    assert chain.shape == (20, 24, 6) and lnp.shape == (20, 24)
+    np.testing.assert_array_equal(lnp[-1], wl.engine.lnprob(chain[-1]))
+    assert isl.island_means().shape == (1, 6)
