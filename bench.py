@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--config", default="C1")
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs that are not part of `value` (copy bandwidth, host-entry latency, device sampler): "
+                         "used under rocprofv3 so that every tile-kernel launch in the trace is the benchmarked one")
     args = ap.parse_args()
 
     # The CPU fan-out leg forks its workers BEFORE anything touches the GPU (a context is not
@@ -258,39 +261,41 @@ def main():
                                  frac=flops / len(wl.pixels) / (tile_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                  algorithmic_flops_per_eval=wl.algorithmic_flops_per_eval,
                                  model="per (line,pixel) 8 + (150 if |x|<8 else 12) + 1; per pixel 30 + 2K + 4")
-        # measured device copy bandwidth next to the vendor peak (read + write of a 1 GiB buffer)
-        src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
+        host_rate = host_lat = sampler_steps = None
+        if not args.no_extras:
+            # measured device copy bandwidth next to the vendor peak (read + write of a 1 GiB buffer)
+            src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+            dst = torch.empty_like(src)
             dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        roof["measured_copy_GBps"] = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del src, dst
-        # PCIe-inclusive rate through the host-buffer entry (never `value`): wall time around
-        # vp_lnprob_batch including H2D theta + D2H lnprob, 100 calls after 5 warm-ups
-        for _ in range(5):
-            wl.engine.lnprob(wl.thetas)
-        lat = []
-        for _ in range(100):
-            th0 = time.perf_counter()
-            wl.engine.lnprob(wl.thetas)
-            lat.append(time.perf_counter() - th0)
-        lat = np.sort(np.array(lat))
-        host_rate = W / float(np.median(lat))
-        host_lat = dict(median_us=1e6 * float(np.median(lat)), p10_us=1e6 * float(lat[10]), p90_us=1e6 * float(lat[90]),
-                        calls=100, walkers_per_call=W)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            roof["measured_copy_GBps"] = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+            # PCIe-inclusive rate through the host-buffer entry (never `value`): wall time around
+            # vp_lnprob_batch including H2D theta + D2H lnprob, 100 calls after 5 warm-ups
+            for _ in range(5):
+                wl.engine.lnprob(wl.thetas)
+            lat = []
+            for _ in range(100):
+                th0 = time.perf_counter()
+                wl.engine.lnprob(wl.thetas)
+                lat.append(time.perf_counter() - th0)
+            lat = np.sort(np.array(lat))
+            host_rate = W / float(np.median(lat))
+            host_lat = dict(median_us=1e6 * float(np.median(lat)), p10_us=1e6 * float(lat[10]), p90_us=1e6 * float(lat[90]),
+                            calls=100, walkers_per_call=W)
 
-        # the walker loop itself on the GPU (vp_stretch_run): real ensemble steps per second, two
-        # half-ensemble passes per step, proposals and accept/reject in HBM -- not part of `value`
-        nst = 300
-        wl.engine.stretch_run(wl.thetas, 20, seed=1, store_chain=False)
-        ts0 = time.perf_counter()
-        wl.engine.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
-        sampler_steps = nst / (time.perf_counter() - ts0)
+            # the walker loop itself on the GPU (vp_stretch_run): real ensemble steps per second, two
+            # half-ensemble passes per step, proposals and accept/reject in HBM -- not part of `value`
+            nst = 300
+            wl.engine.stretch_run(wl.thetas, 20, seed=1, store_chain=False)
+            ts0 = time.perf_counter()
+            wl.engine.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
+            sampler_steps = nst / (time.perf_counter() - ts0)
 
     result = d_out.cpu().numpy()
     if rank == 0:

@@ -3,8 +3,8 @@
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_scalar; rm -rf $OUT; mkdir -p $OUT
 W=${W:-512}
-rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_DCACHE_BUSY_CYCLES SQC_TC_DATA_READ_REQ SQC_TC_STALL GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 2 --walkers $W > $OUT/a.json 2> $OUT/a.err
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_BUSY_CYCLES SQC_TC_INST_REQ SQ_INST_CYCLES_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/b -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 2 --walkers $W > $OUT/b.json 2> $OUT/b.err
+rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_DCACHE_BUSY_CYCLES SQC_TC_DATA_READ_REQ SQC_TC_STALL GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 2 --walkers $W > $OUT/a.json 2> $OUT/a.err
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_BUSY_CYCLES SQC_TC_INST_REQ SQ_INST_CYCLES_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/b -- python3 bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 2 --walkers $W > $OUT/b.json 2> $OUT/b.err
 python3 - <<PY
 import csv, glob, os, collections
 out=os.getcwd()+"/gpurun_out/pmc_scalar"
