@@ -5,7 +5,7 @@
 
 A "step" is one pass of the hot path over one batch: lnprob of the rank's W_local walkers
 (theta already resident in HBM, lnprob left in HBM) plus, for N > 1, the RCCL all-gather of the
-per-walker lnprob vector -- issued asynchronously for chunks of 32 steps and double-buffered
+per-walker lnprob vector -- issued asynchronously for chunks of 128 steps and double-buffered
 (island ensembles, rbvfit_amd/dist.py), every gather completing inside the timed region; the blocking-gather and
 gather-free step times are reported beside it.  Workload at every N: BASELINE.json configs[1] per GPU ("C1":
 MgII 2796/2803, z=0.348, 2 components, 4096 px, 23-tap Gaussian LSF, 512 walkers per GPU => weak
@@ -116,8 +116,8 @@ def cpu_baseline(wl, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="C1")
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,10 +162,17 @@ def main():
     wl = make_workload(args.config, walkers=args.walkers, device_id=local_rank, walker_seed=1 + rank)
     eng = wl.engine
     W, D = wl.thetas.shape
+    # One explicit (non-default) stream carries everything: the engine's kernels are enqueued on its
+    # handle and torch / c10d order their work against it as the current stream.  (The default
+    # stream's handle is 0, which the C ABI reads as "the context's own stream" -- kernels there would
+    # not be ordered with the collectives.)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     d_theta = torch.from_numpy(wl.thetas).cuda()
     d_out = torch.empty(W, dtype=torch.float64, device="cuda")
     gathered = torch.empty(W * world, dtype=torch.float64, device="cuda") if use_dist else None
-    stream = torch.cuda.current_stream()
+    torch.cuda.synchronize()
 
     def launch(out):
         eng.lnprob_device(d_theta.data_ptr(), out.data_ptr(), W, stream.cuda_stream)
@@ -175,7 +182,7 @@ def main():
         # island form (rbvfit_amd.dist): a rank's accept/reject needs its own lnprob only, so the
         # all-gather of a chunk of steps runs on RCCL's stream, double-buffered, under the next chunk's kernels
         from rbvfit_amd.dist import PipelinedGather
-        gather_every = int(os.environ.get("BENCH_GATHER_EVERY", "32"))
+        gather_every = int(os.environ.get("BENCH_GATHER_EVERY", "128"))
         pg = PipelinedGather(launch, W, device="cuda", every=gather_every)
 
     def step():
@@ -203,7 +210,10 @@ def main():
             dt = float(tmax.item())
         return dt
 
-    for _ in range(args.warmup):
+    # The GPU needs ~25 ms of sustained load to reach its steady clocks (scripts/warm_probe.py: 37.9 us
+    # per step in the first 8 ms after an idle period, 32.9 us from ~25 ms on); a sampler runs for
+    # minutes, so the untimed part is made long enough whatever --warmup says.
+    for _ in range(max(args.warmup, 1500)):
         step()
     if pg is not None:
         pg.flush()
@@ -227,7 +237,7 @@ def main():
     roof = None
     if rank == 0:
         eng.profile_enable(True)
-        nprof = min(args.steps, 50)
+        nprof = min(args.steps, 200)
         for _ in range(nprof):
             eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
         torch.cuda.synchronize()

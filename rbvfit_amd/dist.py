@@ -68,9 +68,12 @@ class ShardedPosterior:
 
 
 class DeviceShardedPosterior:
-    """Device-resident variant used by bench.py: theta block and lnprob stay in HBM, the engine is
-    driven through ``vp_lnprob_batch_device`` on torch's current stream and the RCCL all-gather
-    follows on the same stream."""
+    """Device-resident variant: theta block and lnprob stay in HBM, the engine is driven through
+    ``vp_lnprob_batch_device`` and the RCCL all-gather follows on the same stream.  The work runs
+    on a dedicated ``torch.cuda.Stream`` (torch's default stream has handle 0, which the C ABI reads
+    as "the context's own stream" -- the collective would not be ordered behind the kernels); the
+    caller's current stream is made to wait before and after, so it composes with ordinary torch
+    code."""
 
     def __init__(self, engine, theta_block_device, group=None):
         import torch
@@ -78,19 +81,25 @@ class DeviceShardedPosterior:
         self.engine = engine
         self.theta = theta_block_device
         self.W = theta_block_device.shape[0]
-        self.out = torch.empty(self.W, dtype=torch.float64, device=theta_block_device.device)
+        dev = theta_block_device.device
+        self.out = torch.empty(self.W, dtype=torch.float64, device=dev)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
-        self.gathered = (torch.empty(self.W * self.world, dtype=torch.float64, device=theta_block_device.device)
+        self.gathered = (torch.empty(self.W * self.world, dtype=torch.float64, device=dev)
                          if self.world > 1 else self.out)
+        self.stream = torch.cuda.Stream(device=dev)
         self._dist = dist
         self._torch = torch
 
     def step(self):
-        stream = self._torch.cuda.current_stream().cuda_stream
-        self.engine.lnprob_device(self.theta.data_ptr(), self.out.data_ptr(), self.W, stream)
-        if self.world > 1:
-            self._dist.all_gather_into_tensor(self.gathered, self.out, group=self.group)
+        torch = self._torch
+        outer = torch.cuda.current_stream(self.stream.device)
+        self.stream.wait_stream(outer)                      # theta written on the caller's stream
+        with torch.cuda.stream(self.stream):
+            self.engine.lnprob_device(self.theta.data_ptr(), self.out.data_ptr(), self.W, self.stream.cuda_stream)
+            if self.world > 1:
+                self._dist.all_gather_into_tensor(self.gathered, self.out, group=self.group)
+        outer.wait_stream(self.stream)
         return self.gathered
 
 
@@ -98,7 +107,9 @@ class PipelinedGather:
     """Chunked, double-buffered, asynchronous all-gather of a rank-local device vector.
 
     ``launch(out)`` enqueues the local evaluation that fills ``out`` (a (W,) float64 tensor) on
-    the current stream -- e.g. ``Engine.lnprob_device``.  ``step()`` runs it into row k % every of
+    the CURRENT torch stream -- e.g. ``Engine.lnprob_device(..., torch.cuda.current_stream().cuda_stream)``
+    with a non-default stream made current (handle 0 would select the engine's own stream and the
+    collective would not be ordered behind the kernels).  ``step()`` runs it into row k % every of
     the current chunk buffer; when a chunk of ``every`` steps is full, ONE
     ``all_gather_into_tensor(..., async_op=True)`` ships the whole (every, W) block: with RCCL the
     collective runs on the process group's own stream behind an event, so it overlaps the next

@@ -135,7 +135,10 @@ class Engine:
 
     def lnprob_device(self, d_theta_ptr: int, d_out_ptr: int, W: int, stream_ptr: int = 0):
         """Device-resident operands (raw pointers, e.g. ``tensor.data_ptr()``); asynchronous on
-        ``stream_ptr`` (a hipStream_t as int; 0 = the context's stream)."""
+        ``stream_ptr`` (a hipStream_t as int).  0 means the CONTEXT's own non-blocking stream -- which is
+        also what ``torch.cuda.current_stream().cuda_stream`` yields for torch's default stream, so to
+        order the kernels with torch / c10d work make a ``torch.cuda.Stream()`` current and pass its
+        handle (``rbvfit_amd.dist`` does)."""
         self._guard()
         self._check(self._lib.vp_lnprob_batch_device(self._ctx, int(W), self.ndim, C.c_void_p(d_theta_ptr),
                                                      C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr)))

@@ -11,7 +11,7 @@ from rbvfit_amd.dist import PipelinedGather
 wl = make_workload("C1", walkers=512)
 eng, W = wl.engine, 512
 d_theta = torch.from_numpy(wl.thetas).cuda()
-s = torch.cuda.current_stream()
+s = torch.cuda.Stream(); torch.cuda.set_stream(s)
 launch = lambda out: eng.lnprob_device(d_theta.data_ptr(), out.data_ptr(), W, s.cuda_stream)
 for every in (8, 32, 1000):
     pg = PipelinedGather(launch, W, device="cuda", every=every)
