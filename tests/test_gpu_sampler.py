@@ -151,3 +151,18 @@ def test_island_ensemble_with_the_device_sampler():
     assert chain.shape == (20, 24, 6) and lnp.shape == (20, 24)
     np.testing.assert_array_equal(lnp[-1], wl.engine.lnprob(chain[-1]))
     assert isl.island_means().shape == (1, 6)
+
+
+def test_device_sampler_multi_instrument_and_large_ensembles():
+    """Two instruments (C3: tabulated + Gaussian LSF, 24 parameters) and an ensemble above the
+    1024-walker limit of the fused accept/propose launch."""
+    from rbvfit_amd.workloads import make_workload
+    wl = make_workload("C3", walkers=64, pixels=512)
+    pos, lp, chain, clp, nacc = wl.engine.stretch_run(wl.thetas, 6, seed=2)
+    np.testing.assert_array_equal(clp, wl.engine.lnprob(chain.reshape(-1, 24)).reshape(6, 64))
+    assert np.all(chain >= wl.lb) and np.all(chain <= wl.ub) and nacc.sum() > 0
+    wl = make_workload("C1", walkers=1100, pixels=256)
+    pos, lp, chain, clp, nacc = wl.engine.stretch_run(wl.thetas, 4, seed=3)
+    np.testing.assert_array_equal(clp[-1], wl.engine.lnprob(chain[-1]))
+    full = np.concatenate([wl.thetas[None], chain])
+    np.testing.assert_array_equal(np.any(full[1:] != full[:-1], axis=2).sum(axis=0), nacc)
