@@ -147,6 +147,11 @@ int vp_profile_enable(vp_ctx* ctx, int enable);
 int vp_profile_read(vp_ctx* ctx, double* prep_ms, double* tile_ms, double* finalize_ms,
                     int* n_tile_launches);
 
+/* The context's own stream (a hipStream_t, created non-blocking): what hip_stream == NULL selects in the
+ * *_device entry points.  Lets a host framework order its own work against it (e.g.
+ * torch.cuda.ExternalStream(handle).wait_stream(...)). */
+void* vp_ctx_stream(const vp_ctx* ctx);
+
 /* Introspection */
 int vp_num_instruments(const vp_ctx* ctx);
 int vp_ndim(const vp_ctx* ctx);

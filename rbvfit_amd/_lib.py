@@ -53,6 +53,7 @@ SIGNATURES = {
     "vp_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vp_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "vp_profile_read": (C.c_int, [_ctx, _dp, _dp, _dp, C.POINTER(C.c_int)]),
+    "vp_ctx_stream": (C.c_void_p, [_ctx]),
     "vp_num_instruments": (C.c_int, [_ctx]),
     "vp_ndim": (C.c_int, [_ctx]),
     "vp_instrument_pixels": (C.c_int, [_ctx, C.c_int]),
@@ -61,6 +62,29 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def _preload_shared_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own ``libamdhip64.so`` (SONAME
+    ``libamdhip64.so.7``, found through an ``$ORIGIN`` rpath under the file name ``libamdhip64.so``).
+    If this library pulled in ``/opt/rocm/lib/libamdhip64.so.7`` first, a later ``import torch`` would
+    load the bundled copy as a SECOND runtime and fail with "No HIP GPUs are available"; the other
+    order works because our NEEDED entry matches the SONAME already loaded.  So when a torch wheel is
+    installed (found without importing it) its runtime is loaded first and both orders end up on the
+    same copy.  ``RBVFIT_AMD_HIP_RUNTIME=system`` keeps the system runtime."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("RBVFIT_AMD_HIP_RUNTIME", "").lower() == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:              # no torch / unusual layout: the system runtime is used
+        pass
 
 
 def load():
@@ -72,6 +96,7 @@ def load():
         raise RbvfitAmdLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  rbvfit_amd has no CPU fallback.")
+    _preload_shared_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # missing libamdhip64 etc.

@@ -748,6 +748,8 @@ extern "C" int vp_debug_stamps_read(vp_ctx* c, int n, unsigned long long* out) {
 }
 #endif
 
+void* vp_ctx_stream(const vp_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
 int vp_num_instruments(const vp_ctx* c) { return c ? (int)c->inst.size() : 0; }
 int vp_ndim(const vp_ctx* c) { return c ? c->D : 0; }
 int vp_instrument_pixels(const vp_ctx* c, int inst) {

@@ -143,6 +143,36 @@ class Engine:
         self._check(self._lib.vp_lnprob_batch_device(self._ctx, int(W), self.ndim, C.c_void_p(d_theta_ptr),
                                                      C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr)))
 
+    @property
+    def stream_handle(self) -> int:
+        """hipStream_t of the context's own (non-blocking) stream."""
+        self._guard()
+        return int(self._lib.vp_ctx_stream(self._ctx) or 0)
+
+    def lnprob_torch(self, theta, out=None):
+        """lnprob for a CUDA/HIP ``torch.Tensor`` (W, D) float64 on this engine's GPU, ordered with
+        torch's CURRENT stream whatever it is: a non-default stream is used directly; for the default
+        stream (handle 0, which the C ABI would read as "the context's stream") the kernels run on
+        the context's stream, fenced on both sides with ``wait_stream``.  Returns a (W,) tensor."""
+        import torch
+        self._guard()
+        if theta.dtype != torch.float64 or theta.dim() != 2 or not theta.is_cuda or not theta.is_contiguous():
+            raise ValueError("theta must be a contiguous float64 CUDA tensor of shape (W, D)")
+        if theta.device.index != self.device_id or theta.shape[1] != self.ndim:
+            raise ValueError("theta must live on the engine's GPU and have D = ndim columns")
+        W = theta.shape[0]
+        if out is None:
+            out = torch.empty(W, dtype=torch.float64, device=theta.device)
+        cur = torch.cuda.current_stream(theta.device)
+        if cur.cuda_stream != 0:
+            self.lnprob_device(theta.data_ptr(), out.data_ptr(), W, cur.cuda_stream)
+        else:
+            own = torch.cuda.ExternalStream(self.stream_handle, device=theta.device)
+            own.wait_stream(cur)
+            self.lnprob_device(theta.data_ptr(), out.data_ptr(), W, 0)
+            cur.wait_stream(own)
+        return out
+
     def model_flux(self, inst: int, theta, convolved: bool = True) -> np.ndarray:
         self._guard()
         th = self._theta2d(theta)

@@ -60,3 +60,16 @@ def test_product_package_never_imports_the_oracle():
                 code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("#", "//", "of the", "``")))
                 assert not re.search(r"^\s*(import|from)\s+oracle", code, flags=re.M), f
                 assert "voigt_oracle" not in src, f
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """Loading the library first and importing torch afterwards must not map a second HIP runtime
+    (a torch wheel bundles its own libamdhip64.so; two copies leave torch with "No HIP GPUs")."""
+    import subprocess
+    import sys
+    code = ("import rbvfit_amd\nfrom rbvfit_amd import _lib\n_lib.load()\nimport torch\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+            "print(len(libs), libs)\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().startswith("1 "), out.stdout

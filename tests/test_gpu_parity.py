@@ -137,3 +137,25 @@ def test_fork_guard_raises_in_child():
     finally:
         eng._pid = os.getpid()
         eng.close()
+
+
+def test_lnprob_torch_orders_with_default_and_side_streams():
+    """Engine.lnprob_torch: theta produced by torch ops, result consumed by torch ops, on the default
+    stream (handle 0 = "context stream" to the C ABI: fenced through vp_ctx_stream) and on a side stream."""
+    import torch
+    z = load_golden("c0_mgii")
+    with engine_from_fixture(z) as eng:
+        ref = eng.lnprob(z["thetas"])
+        base = torch.from_numpy(z["thetas"]).cuda()
+        for use_side in (False, True):
+            ctx = torch.cuda.stream(torch.cuda.Stream()) if use_side else torch.cuda.stream(torch.cuda.default_stream())
+            with ctx:
+                for rep in range(20):
+                    junk = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")   # keep the stream busy
+                    theta = (base + 0.0 * junk[0, 0]).contiguous()          # depends on the work before it
+                    out = eng.lnprob_torch(theta)
+                    got = (out * 1.0).cpu().numpy()                         # consumed on the same stream
+                    assert np.array_equal(got, ref, equal_nan=True)
+        with pytest.raises(ValueError):
+            eng.lnprob_torch(base.float())
+        assert eng.stream_handle != 0
