@@ -501,11 +501,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
         bool pending[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) pending[r] = false;
-#if defined(VP_ABLATE) && VP_ABLATE == 7
-        if (false) {
-#else
         if (METHOD == 0) {
-#endif
             for (int l0 = 0; l0 < I.L; l0 += 64) {
                 unsigned long long todo[RB];
 #pragma unroll
@@ -706,7 +702,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #pragma unroll
             for (int r = 0; r < RB; ++r) m[r] = fl[min(idx[r], nout - 1) + I.halo_lo];
         } else {
-#if defined(VP_ABLATE) && (VP_ABLATE == 2 || VP_ABLATE == 7)
+#if defined(VP_ABLATE) && VP_ABLATE == 2
             const int kn = 1;
 #else
             const int kn = Kp;                                    // zero taps: fma(0, finite, m) == m exactly

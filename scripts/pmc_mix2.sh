@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_mix2; rm -rf $OUT; mkdir -p $OUT
 W=${W:-512}
-for tag in ${TAGS:-prod 1 2 3 5 7}; do
+for tag in ${TAGS:-prod 1 2 3 5}; do
   lib=""; [ "$tag" != "prod" ] && lib=$PWD/rbvfit_amd/lib/ablate/lib_ablate$tag.so
   RBVFIT_AMD_LIB=$lib rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/$tag -- python3 bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2 --walkers $W > $OUT/$tag.json 2> $OUT/$tag.err
 done
@@ -12,7 +12,7 @@ python3 - <<PY
 import csv, glob, os, collections
 out=os.getcwd()+"/gpurun_out/pmc_mix2"
 W=$W
-for tag in ("prod","1","2","3","5","7"):
+for tag in ("prod","1","2","3","5"):
     acc=collections.defaultdict(list)
     for f in glob.glob(f"{out}/{tag}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
