@@ -483,6 +483,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     //      outer loop so that a line's constants are fetched once and feed RB independent
     //      evaluations.  Chunks that touch a line core (or a line outside the fast domain) are only
     //      flagged; their tau goes to LDS raw and phase B finishes them.
+    bool wave_any = false;                  // did this wave flag any (chunk, line) for phase B?  (wave-uniform)
     for (int base = wid * (64 * RB); base < n_eval; base += TILE_THREADS * RB) {
         double g[RB], wv[RB], tau[RB];
         if (base == wid * (64 * RB)) {                    // first pass: loaded in the prologue
@@ -506,7 +507,11 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 unsigned long long todo[RB];
 #pragma unroll
                 for (int r = 0; r < RB; ++r) todo[r] = 0ull;
+#if defined(VP_ABLATE) && VP_ABLATE == 9
+                const int l1 = l0;                    // timing experiment: no line is evaluated (masks stay empty)
+#else
                 const int l1 = min(I.L, l0 + 64);
+#endif
                 Eager nxt = load_eager(lcw + (size_t)l0 * LC_STRIDE);
                 for (int l = l0; l < l1; ++l) {
                     // far from a whole cluster of components?  one multipole evaluation replaces all of
@@ -595,6 +600,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #pragma unroll
                 for (int r = 0; r < RB; ++r) {
                     pending[r] = pending[r] || (todo[r] != 0ull);
+                    wave_any = wave_any || (todo[r] != 0ull);
                     const int c = (base >> 6) + r;
                     if (lane == 0 && c < nchunks) cmask[c * nwords + (l0 >> 6)] = todo[r];
                 }
@@ -628,16 +634,21 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     //      core radius, then exp.  Single instance of the core code keeps the hot loop's registers
     //      low.  All control flow here is wave-uniform, so lane-held records stay readable.
     if (METHOD == 0) {
-        // stage the Dawson table only if some chunk of this tile needs the core series (uniform)
-        unsigned int anycore = 0u;
-        for (int k = lane; k < nchunks * nwords; k += 64) {
-            const unsigned long long mw = cmask[k];
-            anycore |= (unsigned int)mw | (unsigned int)(mw >> 32);
+        // anything to do?  A single-wave workgroup knows from its own registers (and skips the whole
+        // phase, mask scan included: ~1 us of a 10 us tile without line cores); wider workgroups scan
+        // the masks every wave wrote to LDS.  Uniform over the workgroup either way.
+        bool anyc = wave_any;
+        if (nwaves > 1) {
+            unsigned int anycore = 0u;
+            for (int k = lane; k < nchunks * nwords; k += 64) {
+                const unsigned long long mw = cmask[k];
+                anycore |= (unsigned int)mw | (unsigned int)(mw >> 32);
+            }
+            anyc = __ballot(anycore != 0u) != 0ull;
         }
-        if (__ballot(anycore != 0u) != 0ull) {
-            dawson_to_lds(daw, threadIdx.x, TILE_THREADS);
+        if (anyc) {
+            dawson_to_lds(daw, threadIdx.x, TILE_THREADS);   // staged only when some chunk needs the core series
             __syncthreads();
-        }
         int kth = 0;
         for (int c = 0; c < nchunks; ++c) {
             unsigned int any = 0u;
@@ -681,6 +692,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 }
             }
             if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg_tab(tau, etab);   // NaN survives (poisoned lines)
+        }
         }
         __syncthreads();
     }
