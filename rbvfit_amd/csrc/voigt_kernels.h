@@ -382,7 +382,7 @@ constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span =
 #ifndef VP_RB
 #define VP_RB 3     // measured: RB=3 (91 VGPRs, 5 waves/SIMD) beats RB=2 (79, 6) and RB=4 (109, 4) by 3-5 %
 #endif
-constexpr int FL_PAD = 8;         // LDS doubles after a tile's flux that the zero-padded taps may read
+constexpr int FL_PAD = 16;        // LDS doubles after a tile's flux that the zero-padded taps may read
 constexpr int RB = VP_RB;         // 64-pixel chunks per wave pass (register blocking / ILP)
 
 // s * Horner_M(K, s) for RB independent chunks with the same M; K wave-uniform (SGPR operands).
@@ -700,8 +700,74 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #ifdef VP_STAMP
     st3 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // ---- LSF from LDS (taps broadcast from lanes), chi^2 term, reduce -----------------------------
+    // ---- LSF from LDS, chi^2 term, reduce ------------------------------------------------------
+    //      Each lane produces TWO adjacent output pixels from a sliding window of the flux held in
+    //      registers: per group of 8 taps it reads 10 consecutive doubles as five 16-byte LDS reads
+    //      (lane stride 16 B: conflict-free) for 16 FMAs -- 5 B of LDS traffic per output and tap
+    //      instead of 8 B with one output per lane.  Taps are LDS broadcasts, zero-padded to groups of
+    //      8; the flux is followed by FL_PAD zeros.  Per output the taps are still accumulated in
+    //      ascending order, so the result is bit-identical to the plain loop.
     double acc = 0.0;
+#if !defined(VP_CONV_PLAIN)
+    if (OUT != 2) {
+#if defined(VP_ABLATE) && VP_ABLATE == 2
+        const int kn = 8;
+#else
+        const int kn = Kp;
+#endif
+        constexpr int CG = 2;                                         // pixel pairs per lane and iteration (ILP)
+        for (int ob = 0; ob < nout; ob += 2 * CG * TILE_THREADS) {
+            int o0[CG];
+            const double2* __restrict__ fw[CG];
+            double m0[CG], m1[CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                o0[c] = ob + c * 2 * TILE_THREADS + 2 * (int)threadIdx.x;     // even
+                const int oc = min(o0[c], (nout - 1) & ~1);           // lanes past the end re-read the last pair
+                fw[c] = reinterpret_cast<const double2*>(fl + oc);
+                m0[c] = 0.0; m1[c] = 0.0;
+            }
+            for (int j = 0; j < kn; j += 8) {
+                const double* __restrict__ kb = ktap + j;             // uniform address: LDS broadcasts
+                double f[CG][10];
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        const double2 v = fw[c][(j >> 1) + q];
+                        f[c][2 * q] = v.x; f[c][2 * q + 1] = v.y;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double kj = kb[u];
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) {
+                        m0[c] = __builtin_fma(kj, f[c][u], m0[c]);
+                        m1[c] = __builtin_fma(kj, f[c][u + 1], m1[c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                const int p = p0 + o0[c];
+                if (OUT == 0) {
+                    if (o0[c] < nout) {
+                        const double d = I.flux[p] - m0[c];
+                        acc = __builtin_fma(d * d, I.w[p], acc);      // (flux-model)^2 * inv_sigma2
+                    }
+                    if (o0[c] + 1 < nout) {
+                        const double d = I.flux[p + 1] - m1[c];
+                        acc = __builtin_fma(d * d, I.w[p + 1], acc);
+                    }
+                } else {
+                    if (o0[c] < nout) out[(size_t)w * out_stride + p] = m0[c];
+                    if (o0[c] + 1 < nout) out[(size_t)w * out_stride + p + 1] = m1[c];
+                }
+            }
+        }
+    } else
+#endif
     for (int ib = 0; ib < nout; ib += TILE_THREADS * RB) {
         double m[RB];
         int idx[RB];

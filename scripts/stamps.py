@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["RBVFIT_AMD_LIB"] = os.path.join(ROOT, "rbvfit_amd", "lib", "ablate", "lib_stamp.so")
+os.environ["RBVFIT_AMD_LIB"] = os.path.join(ROOT, "rbvfit_amd", "lib", "ablate", os.environ.get("STAMP_LIB", "lib_stamp.so"))
 from rbvfit_amd.workloads import make_workload
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 wl = make_workload("C1", walkers=W)
