@@ -261,6 +261,7 @@ def main():
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, traffic_source=traffic_src, kernel="vp::tile_kernel<0,0>", avg_kernel_ms=tile_ms,
                     algorithmic_bytes_per_launch=bytes_per_launch, prep_ms=pr["prep_ms"] / nprof,
+                    finalize_ms=pr.get("finalize_ms", 0.0) / nprof,
                     note="kernel is fp64-VALU / latency bound; spectra are shared by all walkers through L2/MALL, "
                          "so measured HBM traffic is far below the algorithmic bytes (DESIGN.md section 4)")
         # secondary roof: fp64 VALU, with the survey's flop model

@@ -242,8 +242,14 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     int sel = ((long)W * c->total_tiles_g[0] <= 3840) ? 1 : 0;
     if (const char* e = getenv("RBVFIT_AMD_GEOM")) sel = atoi(e) ? 1 : 0;
     const int ntot = c->total_tiles_g[sel];
-    const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw, d_out, (int)c->inst.size(), ntot,
-                               c->d_stamps};
+    // Final reduction: fused into the tile kernel (last-arriving tile of a walker, ticket in L2) while the
+    // batch leaves wave slots empty, a launch of its own (one lane per walker) once it fills them: the
+    // ticket's L2 round trips at the end of every tile wave then cost more than one small launch
+    // (measured on C1: equal within noise up to 384 walkers, separate launch +2 % at 512, +4 % at 8192).
+    bool fused = (long)W * c->total_tiles_g[0] < 6144;
+    if (const char* e = getenv("RBVFIT_AMD_FUSED_FINALIZE")) fused = atoi(e) != 0;
+    const vp::FinalizeArgs fin{fused ? c->d_ticket : (unsigned int*)nullptr, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw,
+                               d_out, (int)c->inst.size(), ntot, c->d_stamps};
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
@@ -262,6 +268,13 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             m0 = m2;
         }
         tile_off += geom.ntiles;
+    }
+    if (!fused) {
+        hipLaunchKernelGGL(vp::finalize_kernel, dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, ntot, W, c->d_flags, fin);
+        if (prof) {
+            size_t m3 = prof_mark(c, s);
+            c->spans.push_back({m0, m3, 2});
+        }
     }
     HIP_TRY(c, hipGetLastError());
     return VP_OK;

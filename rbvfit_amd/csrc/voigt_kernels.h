@@ -15,6 +15,7 @@
 //              chi^2 term vs flux / inv_sigma2, wave reduce -> partial[w][tile] (vfit_mcmc.py:309-311)
 //              last-arriving tile of a walker (agent-scope atomics) sums the partials in fixed order
 //              and writes lnprob = -0.5 (sum - sum log w)                      (vfit_mcmc.py:348-353)
+//              -- or, for batches that fill the wave slots, finalize_kernel does (one lane per walker)
 //   Two instances: GENERIC=false (no out-of-line generic Faddeeva, 91 VGPRs, 5 waves/SIMD) and
 //   GENERIC=true (handles walkers flagged by prep; launched only when the prior box allows a > 0.1).
 //
@@ -833,6 +834,10 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
             // 8-byte agent-scope atomics on both sides (write-through store, drained before the
             // ticket; L1-bypassing loads after it) -- placement-independent, no fences needed.
             double* row = out + (size_t)w * out_stride;
+            if (F.ticket == nullptr) {       // large batches: a separate launch sums the partials (finalize_kernel)
+                row[out_offset + t] = tile_sum;
+                return;
+            }
             __hip_atomic_store(row + out_offset + t, tile_sum, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
 #if defined(VP_ABLATE) && VP_ABLATE == 4
@@ -859,6 +864,23 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #endif
         }
     }
+}
+
+// Final reduction as a launch of its own (one lane per walker), used for batches so large that the two
+// L2 round trips of the fused ticket at the end of every tile wave cost more than a launch (~6 % of the
+// tile kernel at 8192 walkers).  Same summation order as the fused path: bit-identical lnprob.
+__global__ __launch_bounds__(64) void finalize_kernel(const double* __restrict__ partial, int stride, int W,
+                                                      const int* __restrict__ flags, FinalizeArgs F) {
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= W || flags[w]) return;                   // out-of-bounds walkers keep the -inf written by prep
+    const double* __restrict__ row = partial + (size_t)w * stride;
+    double total = 0.0;
+    for (int k = 0; k < F.n_inst; ++k) {
+        double sk = 0.0;
+        for (int tt = F.tile_off[k]; tt < F.tile_off[k + 1]; ++tt) sk += row[tt];
+        total += -0.5 * (sk - F.sum_logw[k]);           // vfit_mcmc.py:309-311
+    }
+    F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
 }
 
 // Test hook: H(a_i, x_j) with the production tier logic (wave = 64 consecutive x_j of one a_i).

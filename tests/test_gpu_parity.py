@@ -15,12 +15,14 @@ def oracle():
     return vo
 
 
-@pytest.mark.parametrize("geom", ["auto", "0", "1"])      # tile geometry: by batch size / two-pass / one-pass tiles
-@pytest.mark.parametrize("name", golden_cases())
+@pytest.mark.parametrize("geom", ["auto", "0", "1", "0-sep", "1-sep"])   # tile geometry (by batch size / two-pass /
+@pytest.mark.parametrize("name", golden_cases())                        # one-pass) x final reduction (fused / own launch)
 def test_lnprob_matches_golden(name, geom, monkeypatch):
     z = load_golden(name)
     if geom != "auto":
-        monkeypatch.setenv("RBVFIT_AMD_GEOM", geom)
+        monkeypatch.setenv("RBVFIT_AMD_GEOM", geom[0])
+        if geom.endswith("-sep"):
+            monkeypatch.setenv("RBVFIT_AMD_FUSED_FINALIZE", "0")
     with engine_from_fixture(z) as eng:
         got = eng.lnprob(z["thetas"])
     ref = z["lnprob"]
