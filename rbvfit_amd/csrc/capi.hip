@@ -162,7 +162,13 @@ int ensure_workspace(vp_ctx* c, int W) {
     HIP_TRY(c, hipMalloc((void**)&c->d_theta, (size_t)newW * std::max(c->D, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_out, (size_t)newW * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_lc, (size_t)newW * maxL * vp::LC_STRIDE * sizeof(double)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_partial, (size_t)newW * std::max(c->total_tiles, 1) * sizeof(double)));
+    {
+        const size_t np = (size_t)newW * std::max(c->total_tiles, 1);
+        HIP_TRY(c, hipMalloc((void**)&c->d_partial, np * sizeof(double)));
+        hipLaunchKernelGGL(vp::fill_partials_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, 0, c->d_partial, np);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipDeviceSynchronize());
+    }
     HIP_TRY(c, hipMalloc((void**)&c->d_flags, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMemset(c->d_flags, 0, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMalloc((void**)&c->d_ticket, (size_t)newW * sizeof(unsigned int)));
@@ -242,14 +248,16 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     int sel = ((long)W * c->total_tiles_g[0] <= 3840) ? 1 : 0;
     if (const char* e = getenv("RBVFIT_AMD_GEOM")) sel = atoi(e) ? 1 : 0;
     const int ntot = c->total_tiles_g[sel];
-    // Final reduction: fused into the tile kernel (last-arriving tile of a walker, ticket in L2) while the
-    // batch leaves wave slots empty, a launch of its own (one lane per walker) once it fills them: the
-    // ticket's L2 round trips at the end of every tile wave then cost more than one small launch
-    // (measured on C1: equal within noise up to 384 walkers, separate launch +2 % at 512, +4 % at 8192).
-    bool fused = (long)W * c->total_tiles_g[0] < 6144;
-    if (const char* e = getenv("RBVFIT_AMD_FUSED_FINALIZE")) fused = atoi(e) != 0;
-    const vp::FinalizeArgs fin{fused ? c->d_ticket : (unsigned int*)nullptr, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw,
-                               d_out, (int)c->inst.size(), ntot, c->d_stamps};
+    // Final reduction (bit-identical in every mode, see tile_kernel): while the batch leaves wave slots
+    // empty the walker's last tile waits for its siblings' partials and sums them (no extra launch, no
+    // per-wave ticket); once the batch fills the slots it gets a small launch of its own, which needs no
+    // waiting wave at all.  Measured on C1 (us per pass, modes 2 / 0 / ticket): 2 walkers 18.5 / 19.4 / 20.2,
+    // 256: 25.6 / 26.5 / 26.7, 512: 32.5 / 32.3-33.4 / 33.9, 2048: 89.8 / 88.9 / 92.5, 8192: 321 / 314 / 329.
+    int fmode = ((long)W * c->total_tiles_g[0] < 6144) ? 2 : 0;
+    if (const char* e = getenv("RBVFIT_AMD_FINALIZE")) fmode = atoi(e);      // 0: own launch, 1: ticket, 2: last tile
+    const bool fused = fmode != 0;
+    const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw,
+                               d_out, (int)c->inst.size(), ntot, fmode, c->d_stamps};
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;

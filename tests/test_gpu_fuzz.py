@@ -79,11 +79,11 @@ def test_random_configuration(seed):
         e.add_instrument(wave, flux, inst.inv_sigma2, inst.log_inv_sigma2, **data.engine_kwargs())
         got = e.lnprob(thetas)
         os.environ["RBVFIT_AMD_GEOM"] = "0"              # the two-pass tile geometry and the separate final
-        os.environ["RBVFIT_AMD_FUSED_FINALIZE"] = "0"    # reduction (large batches) as well
+        os.environ["RBVFIT_AMD_FINALIZE"] = "0"          # reduction (large batches) as well
         try:
             got_big = e.lnprob(thetas)
         finally:
-            del os.environ["RBVFIT_AMD_GEOM"], os.environ["RBVFIT_AMD_FUSED_FINALIZE"]
+            del os.environ["RBVFIT_AMD_GEOM"], os.environ["RBVFIT_AMD_FINALIZE"]
         fl = e.model_flux(0, thetas[:3])
         un = e.model_flux(0, thetas[:2], convolved=False)
     np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)

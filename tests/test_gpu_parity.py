@@ -15,14 +15,14 @@ def oracle():
     return vo
 
 
-@pytest.mark.parametrize("geom", ["auto", "0", "1", "0-sep", "1-sep"])   # tile geometry (by batch size / two-pass /
-@pytest.mark.parametrize("name", golden_cases())                        # one-pass) x final reduction (fused / own launch)
+# tile geometry (by batch size / two-pass "0" / one-pass "1") x final reduction (own launch "f0" / ticket "f1" / last tile "f2")
+@pytest.mark.parametrize("geom", ["auto", "0-f0", "0-f1", "0-f2", "1-f0", "1-f1", "1-f2"])
+@pytest.mark.parametrize("name", golden_cases())
 def test_lnprob_matches_golden(name, geom, monkeypatch):
     z = load_golden(name)
     if geom != "auto":
         monkeypatch.setenv("RBVFIT_AMD_GEOM", geom[0])
-        if geom.endswith("-sep"):
-            monkeypatch.setenv("RBVFIT_AMD_FUSED_FINALIZE", "0")
+        monkeypatch.setenv("RBVFIT_AMD_FINALIZE", geom[-1])
     with engine_from_fixture(z) as eng:
         got = eng.lnprob(z["thetas"])
     ref = z["lnprob"]
