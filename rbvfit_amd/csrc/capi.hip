@@ -278,7 +278,21 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         tile_off += geom.ntiles;
     }
     if (!fused) {
-        hipLaunchKernelGGL(vp::finalize_kernel, dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, ntot, W, c->d_flags, fin);
+        vp::FinalizeByValue bv{};
+        const size_t ni = c->inst.size();
+        if (ni <= (size_t)vp::FIN_MAX_INST) {
+            bv.n_inst = (int)ni;
+            int off = 0;
+            for (size_t k = 0; k < ni; ++k) {
+                bv.tile_off[k] = off;
+                off += (sel ? c->inst[k].dev_s : c->inst[k].dev).ntiles;
+                bv.sum_logw[k] = c->inst[k].sum_logw;
+            }
+            bv.tile_off[ni] = off;
+            hipLaunchKernelGGL((vp::finalize_kernel<true>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, ntot, W, c->d_flags, fin, bv);
+        } else {
+            hipLaunchKernelGGL((vp::finalize_kernel<false>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, ntot, W, c->d_flags, fin, bv);
+        }
         if (prof) {
             size_t m3 = prof_mark(c, s);
             c->spans.push_back({m0, m3, 2});

@@ -896,18 +896,31 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 // Final reduction as a launch of its own (one lane per walker), used for batches so large that the two
 // L2 round trips of the fused ticket at the end of every tile wave cost more than a launch (~6 % of the
 // tile kernel at 8192 walkers).  Same summation order as the fused path: bit-identical lnprob.
+constexpr int FIN_MAX_INST = 8;
+struct FinalizeByValue {           // the per-instrument tables in the kernel arguments: no dependent scalar loads
+    int n_inst;
+    int tile_off[FIN_MAX_INST + 1];
+    double sum_logw[FIN_MAX_INST];
+};
+template <bool BYVALUE>
 __global__ __launch_bounds__(64) void finalize_kernel(double* __restrict__ partial, int stride, int W,
-                                                      const int* __restrict__ flags, FinalizeArgs F) {
+                                                      const int* __restrict__ flags, FinalizeArgs F, FinalizeByValue V) {
     const int w = blockIdx.x * 64 + threadIdx.x;
-    if (w >= W || flags[w]) return;                   // out-of-bounds walkers keep the -inf written by prep
+    if (w >= W) return;
     double* __restrict__ row = partial + (size_t)w * stride;
+    const int oob = flags[w];
+    const int n_inst = BYVALUE ? V.n_inst : F.n_inst;
     double total = 0.0;
-    for (int k = 0; k < F.n_inst; ++k) {
+    for (int k = 0; k < n_inst; ++k) {
+        const int t0 = BYVALUE ? V.tile_off[k] : F.tile_off[k], t1 = BYVALUE ? V.tile_off[k + 1] : F.tile_off[k + 1];
         double sk = 0.0;
-        for (int tt = F.tile_off[k]; tt < F.tile_off[k + 1]; ++tt) { sk += row[tt]; row[tt] = __longlong_as_double(PARTIAL_EMPTY); }
-        total += -0.5 * (sk - F.sum_logw[k]);           // vfit_mcmc.py:309-311
+        for (int tt = t0; tt < t1; ++tt) sk += row[tt];
+        total += -0.5 * (sk - (BYVALUE ? V.sum_logw[k] : F.sum_logw[k]));   // vfit_mcmc.py:309-311
     }
+    if (oob) return;                                  // out-of-bounds walkers keep the -inf written by prep
     F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
+    const int tend = BYVALUE ? V.tile_off[n_inst] : F.tile_off[n_inst];
+    for (int tt = 0; tt < tend; ++tt) row[tt] = __longlong_as_double(PARTIAL_EMPTY);
 }
 
 // Workspace initialisation: every chi^2 partial slot starts out empty.
