@@ -16,7 +16,7 @@
 //              last-arriving tile of a walker (agent-scope atomics) sums the partials in fixed order
 //              and writes lnprob = -0.5 (sum - sum log w)                      (vfit_mcmc.py:348-353)
 //              -- or, for batches that fill the wave slots, finalize_kernel does (one lane per walker)
-//   Two instances: GENERIC=false (no out-of-line generic Faddeeva, 91 VGPRs, 5 waves/SIMD) and
+//   Two instances: GENERIC=false (no out-of-line generic Faddeeva, 77 VGPRs, 5 waves/SIMD by LDS) and
 //   GENERIC=true (handles walkers flagged by prep; launched only when the prior box allows a > 0.1).
 //
 // HBM layout: spectra (wave, 1/wave, flux, inv_sigma2) are 4 dense fp64 arrays per instrument,
