@@ -395,18 +395,20 @@ __device__ inline double generic_H(double x, const double* __restrict__ rec, int
 }
 
 // 'fast' method: Tepper-Garcia form exactly as core/voigt_approx.py:69-86 (bug-compatible wings).
-__device__ __forceinline__ double tepper_garcia_H(double x, double a) {
+__device__ __forceinline__ double tepper_garcia_H(double x, double a, const double* __restrict__ et) {
     const double SQRT_PI = 1.7724538509055160273;   // numpy sqrt(pi)
     const double x2 = x * x;
-    const double G = exp(-x2);
+    const double G = exp_neg_tab(x2, et);           // table-driven exp (2e-16), 0 beyond x^2 = 800 like exp()
+    const double asp = a * 0.56418958354775628695;  // a / sqrt(pi) to 1 ulp
     const double eps = fmax(1e-2, 100.0 * fabs(a) / SQRT_PI);
     const double safe = fmax(x2, eps);
     const double numer = G * (4.0 * (safe * safe) + 7.0 * safe + 4.0) - 1.5;
     const double sp1 = safe + 1.0;
     const double denom = safe * (sp1 * sp1);
-    const double H_tg = G - (a / SQRT_PI) * numer / denom;
-    const double H_core = G * (1.0 - 2.0 * a / SQRT_PI);
-    return (x2 < eps) ? H_core : H_tg;
+    const double H_tg = G - asp * numer * fast_rcp(denom);
+    const double H_core = G * (1.0 - 2.0 * asp);
+    const double h = (x2 < eps) ? H_core : H_tg;
+    return (x != x) ? x : h;                        // exp_neg_tab's clamp would swallow a NaN
 }
 
 }  // namespace vp

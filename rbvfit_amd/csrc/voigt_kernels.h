@@ -372,9 +372,9 @@ __device__ __attribute__((noinline)) double cold_line_tau(double wv, double g, c
 }
 
 template <class XP>
-__device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __restrict__ rec) {
+__device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __restrict__ rec, const double* __restrict__ et) {
     const double xf = xp.faithful(rec);
-    return rec[LC_T] * tepper_garcia_H(xf, rec[LC_Y]);
+    return rec[LC_T] * tepper_garcia_H(xf, rec[LC_Y], et);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -613,8 +613,30 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
             for (int l = 0; l < I.L; ++l) {
                 if (I.line_sel >= 0 && l != I.line_sel) continue;
                 const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
+                // Far from the line (every |x| >= 28, i.e. x^2 >= 784): G = exp(-x^2) underflows to exactly 0
+                // in double, so the reference's expression (voigt_approx.py:79-81) reduces to
+                //   H = (a/sqrt(pi)) * 1.5 / (x^2 (x^2+1)^2)      [its x^-6 wing, trap T9]
+                // -- no exp, no division sequence, and the 1-FMA x is plenty (H <= 1e-9 a out here).
+                const double a_l = rec[LC_Y];
+                const double eps_l = fmax(1e-2, 100.0 * fabs(a_l) / 1.7724538509055160273);
+                double xc[RB];
 #pragma unroll
-                for (int r = 0; r < RB; ++r) tau[r] += line_tau_fast(PixelX{wv[r], g[r]}, rec);
+                for (int r = 0; r < RB; ++r) xc[r] = __builtin_fma(rec[LC_A], g[r], -rec[LC_B]);
+                double xmf = fabs(xc[0]);
+#pragma unroll
+                for (int r = 1; r < RB; ++r) xmf = fmin(xmf, fabs(xc[r]));
+                if (eps_l <= 784.0 && VP_NONE_BELOW(xmf, 28.0)) {
+                    const double pref = rec[LC_T] * ((a_l / 1.7724538509055160273) * 1.5);
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const double x2 = xc[r] * xc[r];
+                        const double sp1 = x2 + 1.0;
+                        tau[r] = __builtin_fma(pref, fast_rcp1(x2 * (sp1 * sp1)), tau[r]);
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int r = 0; r < RB; ++r) tau[r] += line_tau_fast(PixelX{wv[r], g[r]}, rec, etab);
             }
         }
 #pragma unroll

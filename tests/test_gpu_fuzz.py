@@ -35,7 +35,8 @@ def _random_case(seed):
     if seed % 7 == 3:                                   # tabulated asymmetric kernel (astropy 'extend' branch)
         j = np.arange(-15, 16)
         taps = np.exp(-0.5 * (j / 2.7) ** 2) * (1 + 0.01 * j) + 0.002
-    model = VoigtModel(cfg, FWHM=fwhm, kernel_taps=taps)
+    method = "fast" if seed % 9 == 4 else "wofz"           # the reference's Tepper-Garcia option (bug-compatible wings)
+    model = VoigtModel(cfg, FWHM=fwhm, kernel_taps=taps, voigt_method=method)
     # wavelength grid around a random subset of the lines; sometimes descending or non-uniform
     c0 = float(rng.choice(centres))
     span = float(rng.choice([6.0, 25.0, 120.0]))
