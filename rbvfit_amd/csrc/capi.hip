@@ -162,13 +162,7 @@ int ensure_workspace(vp_ctx* c, int W) {
     HIP_TRY(c, hipMalloc((void**)&c->d_theta, (size_t)newW * std::max(c->D, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_out, (size_t)newW * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_lc, (size_t)newW * maxL * vp::LC_STRIDE * sizeof(double)));
-    {
-        const size_t np = (size_t)newW * std::max(c->total_tiles, 1);
-        HIP_TRY(c, hipMalloc((void**)&c->d_partial, np * sizeof(double)));
-        hipLaunchKernelGGL(vp::fill_partials_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, 0, c->d_partial, np);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipDeviceSynchronize());
-    }
+    HIP_TRY(c, hipMalloc((void**)&c->d_partial, (size_t)newW * std::max(c->total_tiles, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_flags, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMemset(c->d_flags, 0, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMalloc((void**)&c->d_ticket, (size_t)newW * sizeof(unsigned int)));
@@ -248,13 +242,13 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     int sel = ((long)W * c->total_tiles_g[0] <= 3840) ? 1 : 0;
     if (const char* e = getenv("RBVFIT_AMD_GEOM")) sel = atoi(e) ? 1 : 0;
     const int ntot = c->total_tiles_g[sel];
-    // Final reduction (bit-identical in every mode, see tile_kernel): while the batch leaves wave slots
-    // empty the walker's last tile waits for its siblings' partials and sums them (no extra launch, no
-    // per-wave ticket); once the batch fills the slots it gets a small launch of its own, which needs no
-    // waiting wave at all.  Measured on C1 (us per pass, modes 2 / 0 / ticket): 2 walkers 18.5 / 19.4 / 20.2,
-    // 256: 25.6 / 26.5 / 26.7, 512: 32.5 / 32.3-33.4 / 33.9, 2048: 89.8 / 88.9 / 92.5, 8192: 321 / 314 / 329.
-    int fmode = ((long)W * c->total_tiles_g[0] < 6144) ? 2 : 0;
-    if (const char* e = getenv("RBVFIT_AMD_FINALIZE")) fmode = atoi(e);      // 0: own launch, 1: ticket, 2: last tile
+    // Final reduction (bit-identical either way, see tile_kernel): fused into the tile kernel -- the
+    // last-arriving tile of a walker, by ticket -- while the batch leaves wave slots empty; a small launch of
+    // its own (one lane per walker) once the batch fills them, where the ticket's L2 round trips at the end of
+    // every tile wave cost more than a launch.  Measured on C1 (us per pass, own launch / ticket): 256
+    // walkers 26.5 / 26.7, 512: 32.3 / 33.0-33.9, 2048: 88.9 / 92.5, 8192: 314 / 329.
+    int fmode = ((long)W * c->total_tiles_g[0] < 6144) ? 1 : 0;
+    if (const char* e = getenv("RBVFIT_AMD_FINALIZE")) fmode = atoi(e) ? 1 : 0;      // 0: own launch, 1: ticket
     const bool fused = fmode != 0;
     const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw,
                                d_out, (int)c->inst.size(), ntot, fmode, c->d_stamps};

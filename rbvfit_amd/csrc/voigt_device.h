@@ -224,6 +224,8 @@ __host__ __device__ __forceinline__ int core_terms(double a) {
     return a <= 1e-9 ? 1 : a <= 5e-4 ? 2 : a <= 5e-3 ? 3 : a <= 2e-2 ? 4 : a <= 5e-2 ? 5 : 7;
 }
 
+constexpr int DAW_GLO = 10;       // G = 1 - 2xF has its own polynomial from this interval (|x| >= 5) on
+
 // Core H(a,x) for |x| < 8, 0 <= a <= 0.1 (see the header comment).  `nodd` and `ea2` = exp(a^2)
 // are per-line constants.  Branch-free per lane; the only control flow is wave-uniform.
 __device__ __forceinline__ double core_taylor_H(double x, double a, double ea2, int nodd) {
@@ -237,6 +239,7 @@ __device__ __forceinline__ double core_taylor_H(double x, double a, double ea2, 
         F = __builtin_fma(F, t, cf[k]);
         G = __builtin_fma(G, t, cf[DAW_DEG + 1 + k]);
     }
+    G = (i >= DAW_GLO) ? G : __builtin_fma(-2.0 * ax, F, 1.0);   // same rule as the LDS version below
     const double c = 1.1283791670955125739;          // 2/sqrt(pi)
     double vp = c * F, vc = c * G;                    // v_0, v_1
     const double E = exp_neg(ax * ax);
@@ -259,22 +262,24 @@ __device__ __forceinline__ double core_taylor_H(double x, double a, double ea2, 
     return __builtin_fma(E * ea2, cos_small(2.0 * a * ax), acc);
 }
 
-// Same series with the Dawson table staged in LDS as [interval][k][F,G] pairs (one ds_read_b128 per
-// degree); used by the tile kernel's hot loop.
-constexpr int DAW_LDS_DOUBLES = DAW_NI * 2 * (DAW_DEG + 1);
+// Same series with the Dawson tables staged in LDS; used by the tile kernel's hot loop.
+// LDS copy of the Dawson tables: F for all 16 intervals, G = 1 - 2xF only for |x| >= 5 (intervals
+// DAW_GLO..15).  Below that G is formed from F: its absolute error stays ~1.5e-16, which is what enters H
+// (through a*(2/sqrt(pi))*G, next to a Gaussian term >= 1.4e-11) -- relative effect on H below 8e-15;
+// beyond |x| = 5, where H is the a-term alone, the subtraction would cost up to 2x^2 = 128 ulp of G, and
+// G has its own polynomial.  308 doubles instead of 448: with it a
+// single-wave workgroup fits in 6400 B of LDS (5 allocation granules) -> 6 waves per SIMD.
+constexpr int DAW_F_DOUBLES = DAW_NI * (DAW_DEG + 1);
+constexpr int DAW_LDS_DOUBLES = DAW_F_DOUBLES + (DAW_NI - DAW_GLO) * (DAW_DEG + 1);
 __device__ __forceinline__ void dawson_to_lds(double* __restrict__ daw, int tid, int nthreads) {
-    // all loads first, then all LDS writes (one memory round trip); 448 entries, >= 64 threads
-    double v[7];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-        const int idx = min(tid + u * nthreads, DAW_LDS_DOUBLES - 1);
-        const int i = idx / (2 * (DAW_DEG + 1)), rem = idx % (2 * (DAW_DEG + 1));
-        v[u] = g_dawson[i][rem & 1][rem >> 1];
-    }
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-        const int idx = tid + u * nthreads;
-        if (idx < DAW_LDS_DOUBLES) daw[idx] = v[u];
+    for (int idx = tid; idx < DAW_LDS_DOUBLES; idx += nthreads) {
+        double v;
+        if (idx < DAW_F_DOUBLES) v = g_dawson[idx / (DAW_DEG + 1)][0][idx % (DAW_DEG + 1)];
+        else {
+            const int j = idx - DAW_F_DOUBLES;
+            v = g_dawson[DAW_GLO + j / (DAW_DEG + 1)][1][j % (DAW_DEG + 1)];
+        }
+        daw[idx] = v;
     }
 }
 __device__ __forceinline__ double core_taylor_H_lds(double x, double a, double ea2, int nodd,
@@ -283,14 +288,17 @@ __device__ __forceinline__ double core_taylor_H_lds(double x, double a, double e
     const double ax = fabs(x);
     const int i = min((int)(ax * 2.0), DAW_NI - 1);
     const double t = __builtin_fma(ax, 4.0, -(double)(2 * i + 1));
-    const double2* __restrict__ cf = reinterpret_cast<const double2*>(daw) + i * (DAW_DEG + 1);
-    double2 ck = cf[DAW_DEG];
-    double F = ck.x, G = ck.y;
+    const double* __restrict__ cF = daw + i * (DAW_DEG + 1);
+    double F = cF[DAW_DEG];
 #pragma unroll
-    for (int k = DAW_DEG - 1; k >= 0; --k) {
-        ck = cf[k];
-        F = __builtin_fma(F, t, ck.x);
-        G = __builtin_fma(G, t, ck.y);
+    for (int k = DAW_DEG - 1; k >= 0; --k) F = __builtin_fma(F, t, cF[k]);
+    double G = __builtin_fma(-2.0 * ax, F, 1.0);
+    if (__ballot(i >= DAW_GLO) != 0ull) {             // some lane beyond |x| = 5: G from its own polynomial there
+        const double* __restrict__ cG = daw + DAW_F_DOUBLES + max(i - DAW_GLO, 0) * (DAW_DEG + 1);
+        double Gt = cG[DAW_DEG];
+#pragma unroll
+        for (int k = DAW_DEG - 1; k >= 0; --k) Gt = __builtin_fma(Gt, t, cG[k]);
+        G = (i >= DAW_GLO) ? Gt : G;
     }
     const double c = 1.1283791670955125739;          // 2/sqrt(pi)
     double vp = c * F, vc = c * G;                    // v_0, v_1

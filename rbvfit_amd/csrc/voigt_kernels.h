@@ -51,7 +51,7 @@ struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of 
     double* lnprob;              // (W) output
     int n_inst;
     int total_tiles;             // arrivals per walker over all instruments
-    int mode;                    // 0: finalize_kernel sums; 1: last-arriving tile (ticket); 2: the walker's last tile waits
+    int mode;                    // 0: finalize_kernel sums; 1: the last-arriving tile of the walker does (ticket)
     unsigned long long* stamps;  // diagnostic builds (-DVP_STAMP): 8 time stamps per workgroup, else unused
 };
 
@@ -384,9 +384,7 @@ constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span =
 #ifndef VP_RB
 #define VP_RB 3     // measured: RB=3 (91 VGPRs, 5 waves/SIMD) beats RB=2 (79, 6) and RB=4 (109, 4) by 3-5 %
 #endif
-constexpr long long PARTIAL_EMPTY = 0x7FF8A5A5A5A5A5A5ll;   // "no partial yet": a NaN payload no arithmetic result has
-                                                           // (computed NaNs are canonicalised before they are stored)
-constexpr int FL_PAD = 16;        // LDS doubles after a tile's flux that the zero-padded taps may read
+constexpr int FL_PAD = 10;        // LDS doubles after a tile's flux that the zero-padded taps may read
 constexpr int RB = VP_RB;         // 64-pixel chunks per wave pass (register blocking / ILP)
 
 // s * Horner_M(K, s) for RB independent chunks with the same M; K wave-uniform (SGPR operands).
@@ -731,7 +729,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     //      registers: per group of 8 taps it reads 10 consecutive doubles as five 16-byte LDS reads
     //      (lane stride 16 B: conflict-free) for 16 FMAs -- 5 B of LDS traffic per output and tap
     //      instead of 8 B with one output per lane.  Taps are LDS broadcasts, zero-padded to groups of
-    //      8; the flux is followed by FL_PAD zeros.  Per output the taps are still accumulated in
+    //      8; the flux is followed by FL_PAD zeros (the window reads at most 9 doubles past the last one).  Per output the taps are still accumulated in
     //      ascending order, so the result is bit-identical to the plain loop.
     double acc = 0.0;
 #if !defined(VP_CONV_PLAIN)
@@ -854,56 +852,35 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
         if (threadIdx.x == 0) {
             double tile_sum = red[0];
             for (int k = 1; k < nwaves; ++k) tile_sum += red[k];
-            // Publish this tile's partial; someone sums a walker's partials in fixed order (bit-identical
-            // whichever way).  Slots are "empty" (PARTIAL_EMPTY) between launches.
-            //   mode 0  a finalize_kernel launch does (kernel boundary orders everything);
-            //   mode 1  the workgroup that draws the walker's last ticket does (two L2 round trips at the
-            //           end of every wave);
-            //   mode 2  the walker's LAST tile does: every other wave stores and leaves at once; the last
-            //           tile -- dispatched after all its siblings, which depend on nothing, so they always
-            //           finish -- re-reads each slot until its value has landed (bounded), sums, and empties
-            //           the slots again.  No per-wave round trip, no extra launch.
-            // 8-byte agent-scope atomics on both sides (write-through stores, L1-bypassing loads), no fences.
+            // Publish this tile's partial; the partials of a walker are then summed in fixed order
+            // (bit-identical either way):
+            //   mode 0  by a finalize_kernel launch (the kernel boundary orders everything);
+            //   mode 1  by the workgroup that draws the walker's last ticket: hand-off by 8-byte agent-scope
+            //           atomics on both sides (write-through store, drained before the ticket; L1-bypassing
+            //           loads after it) -- placement-independent, no fences, and no wave ever waits for
+            //           another one.
             double* row = out + (size_t)w * out_stride;
-            const double mine = (tile_sum != tile_sum) ? __longlong_as_double(0x7FF8000000000000ll) : tile_sum;
             const int myslot = out_offset + t;
             if (F.mode == 0) {
-                row[myslot] = mine;
+                row[myslot] = tile_sum;
                 return;
             }
-            __hip_atomic_store(row + myslot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + myslot, tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(VP_ABLATE) && VP_ABLATE == 4
             return;
 #endif
-            bool sum_now;
-            if (F.mode == 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned int ticket = __hip_atomic_fetch_add(F.ticket + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sum_now = ticket == (unsigned int)(F.total_tiles - 1);
-                if (sum_now) __hip_atomic_store(F.ticket + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                sum_now = myslot == F.total_tiles - 1;
-            }
-            if (sum_now) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int ticket = __hip_atomic_fetch_add(F.ticket + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == (unsigned int)(F.total_tiles - 1)) {
                 double total = 0.0;
                 for (int k = 0; k < F.n_inst; ++k) {
                     double sk = 0.0;
-                    for (int tt = F.tile_off[k]; tt < F.tile_off[k + 1]; ++tt) {
-                        double v = mine;
-                        if (tt != myslot) {
-                            v = __hip_atomic_load(row + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            for (int spin = 0; __double_as_longlong(v) == PARTIAL_EMPTY && spin < (1 << 21); ++spin) {
-                                __builtin_amdgcn_s_sleep(8);
-                                v = __hip_atomic_load(row + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
-                        sk += v;
-                    }
+                    for (int tt = F.tile_off[k]; tt < F.tile_off[k + 1]; ++tt)
+                        sk += (tt == myslot) ? tile_sum : __hip_atomic_load(row + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     total += -0.5 * (sk - F.sum_logw[k]);           // vfit_mcmc.py:309-311
                 }
                 F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
-                for (int tt = 0; tt < F.total_tiles; ++tt)
-                    __hip_atomic_store(row + tt, __longlong_as_double(PARTIAL_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(F.ticket + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #ifdef VP_STAMP
             if (F.stamps) {     // diagnostic only: wall-clock stamps (100 MHz) of this workgroup's phases
@@ -941,14 +918,6 @@ __global__ __launch_bounds__(64) void finalize_kernel(double* __restrict__ parti
     }
     if (oob) return;                                  // out-of-bounds walkers keep the -inf written by prep
     F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
-    const int tend = BYVALUE ? V.tile_off[n_inst] : F.tile_off[n_inst];
-    for (int tt = 0; tt < tend; ++tt) row[tt] = __longlong_as_double(PARTIAL_EMPTY);
-}
-
-// Workspace initialisation: every chi^2 partial slot starts out empty.
-__global__ void fill_partials_kernel(double* __restrict__ p, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = __longlong_as_double(PARTIAL_EMPTY);
 }
 
 // Test hook: H(a_i, x_j) with the production tier logic (wave = 64 consecutive x_j of one a_i).
