@@ -237,9 +237,10 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     const bool prof = c->profiling;
     size_t m0 = prof ? prof_mark(c, s) : 0;
     // Geometry: a batch whose full-size tiles would leave most wave slots empty is cut into one-pass
-    // tiles instead (twice the workgroups, half the per-wave latency): measured better up to 256
-    // walkers x 12 tiles and worse from 384 x 12 on (256 CUs x 4 SIMDs x 5 waves = 5120 slots).
-    int sel = ((long)W * c->total_tiles_g[0] <= 3840) ? 1 : 0;
+    // tiles instead (twice the workgroups, half the per-wave latency): measured better up to 384
+    // walkers x 12 tiles (30.2 vs 31.1 us), equal at 448, worse at 512 (256 CUs x 4 SIMDs x 6 waves =
+    // 6144 slots).
+    int sel = ((long)W * c->total_tiles_g[0] <= 4800) ? 1 : 0;
     if (const char* e = getenv("RBVFIT_AMD_GEOM")) sel = atoi(e) ? 1 : 0;
     const int ntot = c->total_tiles_g[sel];
     // Final reduction (bit-identical either way, see tile_kernel): fused into the tile kernel -- the
