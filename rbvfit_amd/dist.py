@@ -131,6 +131,8 @@ class PipelinedGather:
         self.out = [torch.empty(self.every, self.W, dtype=torch.float64, device=device) for _ in range(depth)]
         self.full = ([torch.empty(self.world, self.every, self.W, dtype=torch.float64, device=device)
                       for _ in range(depth)] if self.on else [o.view(1, self.every, self.W) for o in self.out])
+        # row views made once: indexing a tensor costs ~2 us of host time per pass otherwise
+        self._row = [[o[j] for j in range(self.every)] for o in self.out] if self.every <= 4096 else None
         self.work = [None] * depth
         self.rows = [0] * depth          # valid rows in each shipped chunk
         self.k = 0                       # steps taken
@@ -153,7 +155,7 @@ class PipelinedGather:
         i = c % self.depth
         if j == 0:
             self._wait(i)                # the collective that last read this buffer
-        row = self.out[i][j]
+        row = self._row[i][j] if self._row is not None else self.out[i][j]
         self.launch(row)
         self.k += 1
         if j == self.every - 1:
