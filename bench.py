@@ -1,19 +1,34 @@
 #!/usr/bin/env python
 """bench.py -- walker-lnprob evals/sec on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torchrun)
+    python bench.py --gpus N --steps K --warmup W [--config C1|C2|C3|C4] [--strong] [--walkers n]
 
-A "step" is one pass of the hot path over one batch: lnprob of the rank's W_local walkers
-(theta already resident in HBM, lnprob left in HBM) plus, for N > 1, the RCCL all-gather of the
-per-walker lnprob vector -- issued asynchronously for chunks of 128 steps and double-buffered
-(island ensembles, rbvfit_amd/dist.py), every gather completing inside the timed region; the blocking-gather and
-gather-free step times are reported beside it.  Workload at every N: BASELINE.json configs[1] per GPU ("C1":
-MgII 2796/2803, z=0.348, 2 components, 4096 px, 23-tap Gaussian LSF, 512 walkers per GPU => weak
-scaling).  One JSON line on rank 0.
+Works as typed for any N: with N > 1 and no torchrun environment the script starts N ranks itself
+(``python -m torch.distributed.run`` as a CHILD process, before anything in this process touches
+the GPU) and relays rank 0's JSON line; under torchrun (how the driver starts it) it is a rank.
+
+A "step" is one pass of the hot path over one batch: lnprob of the rank's block of walkers (theta
+already resident in HBM, lnprob left in HBM) and, for N > 1, the blocking RCCL all-gather of the
+per-walker lnprob vector that a single ensemble needs before its next half-step (north_star's
+"RCCL gather of per-walker lnprob"; the *strict* form).  The island form (every rank samples its
+own walkers, gathers shipped asynchronously in chunks) and the gather-free time are reported
+beside it in ``gather``.
+
+Workload: BASELINE.json configs[1] per GPU by default ("C1": MgII 2796/2803, z=0.348, 2
+components, 4096 px, 23-tap Gaussian LSF, 512 walkers per GPU => weak scaling).  ``--config
+C2|C3|C4`` selects the other configs (per-GPU share of their walker count: C2 1024, C3 2048/8,
+C4 4096/8); ``--strong`` fixes the config's TOTAL walker count and splits it W/N.
+
+Timing: W untimed warm-up steps (raised to what the GPU needs to reach steady clocks; the number
+actually run is ``warmup_effective``), then ``repeats`` blocks of EXACTLY K steps, each bracketed
+by barrier + synchronize on both sides and max-reduced over ranks; ``ms_per_step`` is the MEDIAN
+block (>= 0.25 s of timed passes in total, so a short ``--steps`` is not a one-shot sample).
+One JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,6 +39,91 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TFLOPS = 78.6   # fp64 vector = half the 157.3 TF fp32 vector rate of the same guide
+
+WORKLOAD_LABEL = {
+    "C0": "C0: MgII 2796/2803 z=0.348, 2 components, 4096 px, 23-tap Gaussian LSF",
+    "C1": "C1: MgII 2796/2803 z=0.348, 2 components, 4096 px, 23-tap Gaussian LSF",
+    "C2": "C2: MgII+FeII+CIV, 8 components (19 lines), 16384 px, 23-tap Gaussian LSF",
+    "C3": "C3: joint 2-instrument fit (101-tap tabulated COS-like LSF + 9-tap Gaussian), 8 components (19 lines), 2 x 8192 px",
+    "C4": "C4: stress, 4 MgII systems x 8 components (64 lines), 65536 px, 23-tap Gaussian LSF",
+}
+# total walkers of the config (BASELINE.json) and the GPU count it is quoted on
+CONFIG_WALKERS = {"C0": (50, 1), "C1": (512, 1), "C2": (1024, 1), "C3": (2048, 8), "C4": (4096, 8)}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", default="C1", choices=sorted(WORKLOAD_LABEL))
+    ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default: the config's per-GPU share)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the config's TOTAL walker count (or --walkers x 1) split over the GPUs")
+    ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps passes (0 = enough for 0.25 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs that are not part of `value` (copy bandwidth, host-entry latency, device sampler): "
+                         "used under rocprofv3 so that every tile-kernel launch in the trace is the benchmarked one")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU-only check of the N-rank launcher: gloo rendezvous + all-gather of a synthetic vector, no GPU")
+    return ap.parse_args(argv)
+
+
+# ---- N > 1 typed directly: start the ranks as child processes -----------------------------------
+def launch_ranks(args, argv):
+    """Parent of an N-rank run.  Nothing here initialises the GPU (device_count() does not), and the
+    ranks are fresh child interpreters -- a process that has touched the GPU is never re-exec'ed."""
+    if not args.selftest_launcher:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}\n")
+            return 2
+    port = 20000 + (os.getpid() * 7919) % 20000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last = None
+    for ln in proc.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and ln.endswith("}"):
+            last = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    rc = proc.wait()
+    if last is not None:
+        print(last, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        rc = 1
+    return rc
+
+
+def selftest_rank():
+    """Rank body of --selftest-launcher: the rendezvous, barrier, max-reduce and all-gather the real
+    ranks use, over gloo, on a synthetic per-rank vector."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    W = 5
+    local = torch.arange(W, dtype=torch.float64) + 1000.0 * rank
+    full = torch.empty(W * world, dtype=torch.float64)
+    dist.barrier()
+    dist.all_gather_into_tensor(full, local)
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = bool(torch.equal(full, torch.cat([torch.arange(W, dtype=torch.float64) + 1000.0 * r for r in range(world)]))
+              and t.item() == world - 1)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_ranks": world, "backend": "gloo", "ok": ok}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 # ---- CPU fan-out leg (SURVEY 8d-ii): the reference's Pool.map over walker rows --------------------
@@ -74,13 +174,7 @@ def cpu_baseline(wl, budget_s=12.0):
     """Oracle (NumPy/SciPy restatement of the reference path) timed serially on this box's host
     cores: single-theta lnprob over the same walker rows, what emcee does with pool=None."""
     from oracle import voigt_oracle as vo           # checker / baseline only, never the product
-    insts = []
-    for data, (wave, flux, err) in zip(wl.tables, wl.spectra):
-        od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors,
-                                data.N_indices, data.b_indices, data.v_indices,
-                                data.taps if data.taps is not None else np.zeros(0), data.lsf_mode,
-                                data.voigt_method)
-        insts.append(vo.OracleInstrument.from_error(od, wave, flux, err))
+    insts = _oracle_instruments(vo, _describe(wl))
     vo.lnprob(wl.thetas[0], wl.lb, wl.ub, insts)            # warm-up
     n, t0 = 0, time.perf_counter()
     vals = []
@@ -98,34 +192,24 @@ def cpu_baseline(wl, budget_s=12.0):
         from oracle import c_oracle
         co = c_oracle.COracle(insts, wl.lb, wl.ub)
         cores = min(16, len(os.sched_getaffinity(0)))     # the GPU box's CPU share per GPU
-        co.lnprob_batch(wl.thetas[:cores], nthreads=cores)
+        sub = wl.thetas[:max(cores, min(len(wl.thetas), 64))]
+        co.lnprob_batch(sub[:cores], nthreads=cores)
         t0 = time.perf_counter()
         reps = 0
         while time.perf_counter() - t0 < 4.0:
-            cvals = co.lnprob_batch(wl.thetas, nthreads=cores)
+            cvals = co.lnprob_batch(sub, nthreads=cores)
             reps += 1
         dtc = time.perf_counter() - t0
-        base["c_openmp"] = dict(value=reps * len(wl.thetas) / dtc, cores=cores, kind="port",
-                                sample=f"{reps} x {len(wl.thetas)} walkers, oracle/voigt_oracle.c, OpenMP",
-                                max_rel_vs_numpy_oracle=float(np.max(np.abs(cvals[:len(vals)] / np.array(vals[:len(cvals)]) - 1))))
+        m = min(len(cvals), len(vals))
+        base["c_openmp"] = dict(value=reps * len(sub) / dtc, cores=cores, kind="port",
+                                sample=f"{reps} x {len(sub)} walkers, oracle/voigt_oracle.c, OpenMP",
+                                max_rel_vs_numpy_oracle=float(np.max(np.abs(cvals[:m] / np.array(vals[:m]) - 1))))
     except Exception as e:                                   # the C oracle is optional for the baseline
         base["c_openmp"] = {"error": str(e)}
     return base, np.array(vals)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", default="C1")
-    ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default: the config's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true",
-                    help="skip the legs that are not part of `value` (copy bandwidth, host-entry latency, device sampler): "
-                         "used under rocprofv3 so that every tile-kernel launch in the trace is the benchmarked one")
-    args = ap.parse_args()
-
+def rank_main(args):
     # The CPU fan-out leg forks its workers BEFORE anything touches the GPU (a context is not
     # fork-safe and forked children must not hold the device); they idle until the bench is done.
     pool, pool_cores = None, 0
@@ -141,8 +225,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}; {torch.cuda.device_count()} visible "
+                         "(rbvfit_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     # BENCH_FORCE_DIST=1 exercises the RCCL path (init + all_gather) even with a single rank
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
@@ -158,8 +245,17 @@ def main():
         dist.barrier()
     from rbvfit_amd.workloads import make_workload
 
+    # walkers per rank: weak = the config's per-GPU share whatever N; strong = its total split W/N
+    tot, quoted_on = CONFIG_WALKERS[args.config]
+    if args.strong:
+        total = args.walkers if args.walkers is not None else tot
+        if total % world:
+            raise SystemExit(f"bench.py: --strong needs the walker count ({total}) divisible by --gpus ({world})")
+        w_local = total // world
+    else:
+        w_local = args.walkers if args.walkers is not None else tot // quoted_on
     # every rank owns a different block of walkers of the same ensemble (walker_seed = rank)
-    wl = make_workload(args.config, walkers=args.walkers, device_id=local_rank, walker_seed=1 + rank)
+    wl = make_workload(args.config, walkers=w_local, device_id=local_rank, walker_seed=1 + rank)
     eng = wl.engine
     W, D = wl.thetas.shape
     # One explicit (non-default) stream carries everything: the engine's kernels are enqueued on its
@@ -177,19 +273,11 @@ def main():
     def launch(out):
         eng.lnprob_device(d_theta.data_ptr(), out.data_ptr(), W, stream.cuda_stream)
 
-    pg = None
-    if use_dist:
-        # island form (rbvfit_amd.dist): a rank's accept/reject needs its own lnprob only, so the
-        # all-gather of a chunk of steps runs on RCCL's stream, double-buffered, under the next chunk's kernels
-        from rbvfit_amd.dist import PipelinedGather
-        gather_every = int(os.environ.get("BENCH_GATHER_EVERY", "128"))
-        pg = PipelinedGather(launch, W, device="cuda", every=gather_every)
-
-    def step():
-        if pg is not None:
-            pg.step()
-        else:
-            launch(d_out)
+    def strict_step():
+        """One pass of a single W_total-walker ensemble: local block, then every rank gets the whole vector."""
+        launch(d_out)
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, d_out)
 
     def timed(fn, n, drain=None):
         if use_dist:
@@ -210,34 +298,41 @@ def main():
             dt = float(tmax.item())
         return dt
 
+    def blocks(fn, n, repeats, drain=None):
+        ts = [timed(fn, n, drain) for _ in range(repeats)]
+        return float(np.median(ts)), ts
+
     # The GPU needs ~25 ms of sustained load to reach its steady clocks (scripts/warm_probe.py: 37.9 us
     # per step in the first 8 ms after an idle period, 32.9 us from ~25 ms on); a sampler runs for
-    # minutes, so the untimed part is made long enough whatever --warmup says.
-    for _ in range(max(args.warmup, 1500)):
-        step()
-    if pg is not None:
-        pg.flush()
-    elapsed = timed(step, args.steps, drain=pg.flush if pg is not None else None)
+    # minutes, so the untimed part is made long enough whatever --warmup says (>= 50 ms of passes).
+    t_probe = timed(strict_step, 10) / 10
+    warm_eff = max(args.warmup, int(min(1500, max(20, 0.05 / max(t_probe, 1e-6)))))
+    for _ in range(warm_eff):
+        strict_step()
+    repeats = args.repeats if args.repeats > 0 else int(min(200, max(3, np.ceil(0.25 / max(args.steps * t_probe, 1e-9)))))
+    elapsed, block_times = blocks(strict_step, args.steps, repeats)
 
-    # strict single-ensemble form (every rank needs the full vector before the next half-step):
-    # blocking all-gather after each pass; and the gather-free form -- neither is `value`
-    sync_ms = nogather_ms = None
+    # island form (rbvfit_amd.dist): a rank's accept/reject needs its own lnprob only, so the all-gather of a
+    # chunk of steps runs on RCCL's stream, double-buffered, under the next chunk's kernels; and the gather-free
+    # form -- neither is `value`
+    island_ms = nogather_ms = None
     if use_dist:
-        def sync_step():
-            launch(d_out)
-            dist.all_gather_into_tensor(gathered, d_out)
-        for _ in range(min(args.warmup, 5)):
-            sync_step()
-        sync_ms = 1e3 * timed(sync_step, args.steps) / args.steps
-        nogather_ms = 1e3 * timed(lambda: launch(d_out), args.steps) / args.steps
+        from rbvfit_amd.dist import PipelinedGather
+        gather_every = int(os.environ.get("BENCH_GATHER_EVERY", "128"))
+        pg = PipelinedGather(launch, W, device="cuda", every=gather_every)
+        for _ in range(min(warm_eff, 2 * gather_every)):
+            pg.step()
+        pg.flush()
+        island_ms = 1e3 * blocks(pg.step, args.steps, min(repeats, 20), drain=pg.flush)[0] / args.steps
         last = pg.chunk(0)
         assert torch.equal(last[rank, last.shape[1] - 1], d_out), "pipelined gather differs from the local block"
+        nogather_ms = 1e3 * blocks(lambda: launch(d_out), args.steps, min(repeats, 20))[0] / args.steps
 
     # ---- roofline leg: HIP events around the tile kernel on its launch stream (rank 0) -------
     roof = None
     if rank == 0:
         eng.profile_enable(True)
-        nprof = min(args.steps, 200)
+        nprof = min(max(args.steps, 20), 200)
         for _ in range(nprof):
             eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
         torch.cuda.synchronize()
@@ -247,30 +342,28 @@ def main():
         bytes_per_launch = wl.algorithmic_bytes_per_eval * W / len(wl.pixels)
         achieved = bytes_per_launch / (tile_ms * 1e-3) / 1e9
         # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 per the gfx950 guide
-        # + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command): profiles/<round>_pmc.json
+        # + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command): profiles/<round>[_<config>]_pmc.json
         traffic, traffic_src = None, None
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-            if cands:
-                pm = json.load(open(cands[-1]))
+            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+                pm = json.load(open(cand))
                 if pm.get("config") == args.config and pm.get("walkers_per_gpu") == W:
-                    traffic, traffic_src = pm["tile_kernel_hbm_bytes_per_launch"], os.path.basename(cands[-1])
+                    traffic, traffic_src = pm["tile_kernel_hbm_bytes_per_launch"], os.path.basename(cand)
+                    break
         except Exception:
             pass
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, traffic_source=traffic_src, kernel="vp::tile_kernel<0,0>", avg_kernel_ms=tile_ms,
-                    algorithmic_bytes_per_launch=bytes_per_launch, prep_ms=pr["prep_ms"] / nprof,
-                    finalize_ms=pr.get("finalize_ms", 0.0) / nprof,
+                    traffic=traffic, traffic_source=traffic_src, kernel=pr.get("kernel", "vp::tile_kernel"), avg_kernel_ms=tile_ms,
+                    algorithmic_bytes_per_launch=bytes_per_launch, launches_per_step=pr["n_tile_launches"] / nprof,
+                    prep_ms=pr["prep_ms"] / nprof, finalize_ms=pr.get("finalize_ms", 0.0) / nprof,
                     note="kernel is fp64-VALU / latency bound; spectra are shared by all walkers through L2/MALL, "
                          "so measured HBM traffic is far below the algorithmic bytes (DESIGN.md section 4)")
         # secondary roof: fp64 VALU, with the survey's flop model
         flops = wl.algorithmic_flops_per_eval * W
-        step_s = elapsed / args.steps
-        roof["valu_fp64"] = dict(bound="valu_fp64", unit="TFLOP/s", peak=FP64_VALU_PEAK_TFLOPS,
-                                 achieved=flops / len(wl.pixels) / (tile_ms * 1e-3) / 1e12,
-                                 frac=flops / len(wl.pixels) / (tile_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                 algorithmic_flops_per_eval=wl.algorithmic_flops_per_eval,
+        vt = flops / len(wl.pixels) / (tile_ms * 1e-3) / 1e12
+        roof["valu_fp64"] = dict(bound="valu_fp64", unit="TFLOP/s", peak=FP64_VALU_PEAK_TFLOPS, achieved=vt,
+                                 frac=vt / FP64_VALU_PEAK_TFLOPS, algorithmic_flops_per_eval=wl.algorithmic_flops_per_eval,
                                  model="per (line,pixel) 8 + (150 if |x|<8 else 12) + 1; per pixel 30 + 2K + 4")
         host_rate = host_lat = sampler_steps = None
         if not args.no_extras:
@@ -288,50 +381,60 @@ def main():
             del src, dst
             # PCIe-inclusive rate through the host-buffer entry (never `value`): wall time around
             # vp_lnprob_batch including H2D theta + D2H lnprob, 100 calls after 5 warm-ups
-            for _ in range(5):
+            ncall = 100 if args.config in ("C0", "C1") else 10
+            for _ in range(3):
                 wl.engine.lnprob(wl.thetas)
             lat = []
-            for _ in range(100):
+            for _ in range(ncall):
                 th0 = time.perf_counter()
                 wl.engine.lnprob(wl.thetas)
                 lat.append(time.perf_counter() - th0)
             lat = np.sort(np.array(lat))
             host_rate = W / float(np.median(lat))
-            host_lat = dict(median_us=1e6 * float(np.median(lat)), p10_us=1e6 * float(lat[10]), p90_us=1e6 * float(lat[90]),
-                            calls=100, walkers_per_call=W)
+            host_lat = dict(median_us=1e6 * float(np.median(lat)), p10_us=1e6 * float(lat[ncall // 10]),
+                            p90_us=1e6 * float(lat[(9 * ncall) // 10]), calls=ncall, walkers_per_call=W)
 
             # the walker loop itself on the GPU (vp_stretch_run): real ensemble steps per second, two
             # half-ensemble passes per step, proposals and accept/reject in HBM -- not part of `value`
-            nst = 300
-            wl.engine.stretch_run(wl.thetas, 20, seed=1, store_chain=False)
-            ts0 = time.perf_counter()
-            wl.engine.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
-            sampler_steps = nst / (time.perf_counter() - ts0)
+            if W % 2 == 0:
+                nst = 300 if args.config in ("C0", "C1") else 20
+                wl.engine.stretch_run(wl.thetas, max(2, nst // 15), seed=1, store_chain=False)
+                ts0 = time.perf_counter()
+                wl.engine.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
+                sampler_steps = nst / (time.perf_counter() - ts0)
 
     result = d_out.cpu().numpy()
     if rank == 0:
         evals = W * world * args.steps
         line = {
             "metric": "walker-lnprob evals/sec", "value": evals / elapsed, "unit": "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm_eff,
+            "repeats": repeats, "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_min_block": 1e3 * min(block_times) / args.steps,
+            "ms_per_step_max_block": 1e3 * max(block_times) / args.steps,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: MgII 2796/2803 z=0.348, 2 components, 4096 px, 23-tap Gaussian LSF"
-                                   if args.config in ("C0", "C1") else args.config,
+            "config": {"workload": WORKLOAD_LABEL[args.config],
                        "walkers_per_gpu": W, "walkers_total": W * world, "ndim": D, "n_lines": wl.n_lines,
-                       "pixels": wl.pixels, "parallelism": f"walker-shard x{world}" + (" + RCCL all_gather" if world > 1 else "")},
-            "mcmc_steps_per_sec": (evals / elapsed) / (W * world),
+                       "pixels": wl.pixels,
+                       "parallelism": f"walker-shard x{world}" + (" + blocking RCCL all_gather per pass" if world > 1 else "")},
+            "passes_per_sec": args.steps / elapsed,
+            "mcmc_steps_per_sec": sampler_steps,
+            "mcmc_steps_per_sec_note": "device-resident stretch move (vp_stretch_run): one ensemble step = two half-ensemble "
+                                       "lnprob passes + propose/accept kernels; rank 0's walkers",
             "host_entry_evals_per_sec_pcie_inclusive": host_rate,
             "host_entry_latency": host_lat,
-            "device_sampler_steps_per_sec": sampler_steps,
             "roofline": roof,
         }
         if use_dist:
-            line["gather"] = {"mode": f"async all_gather_into_tensor of {gather_every}-step chunks, double-buffered, "
-                                      "overlapped with the following passes",
-                              "ms_per_step_blocking_gather": sync_ms, "ms_per_step_without_gather": nogather_ms,
-                              "blocking_gather_cost_us": 1e3 * (sync_ms - nogather_ms),
-                              "overlapped_gather_cost_us": 1e3 * (line["ms_per_step"] - nogather_ms)}
+            line["gather"] = {"value_form": "strict: blocking all_gather_into_tensor of the per-walker lnprob after every pass",
+                              "ms_per_step_island_form": island_ms,
+                              "island_form": f"async all_gather_into_tensor of {gather_every}-step chunks, double-buffered, "
+                                             "overlapped with the following passes (rbvfit_amd.dist.PipelinedGather)",
+                              "island_form_evals_per_sec": W * world / (island_ms * 1e-3),
+                              "ms_per_step_without_gather": nogather_ms,
+                              "blocking_gather_cost_us": 1e3 * (line["ms_per_step"] - nogather_ms),
+                              "overlapped_gather_cost_us": 1e3 * (island_ms - nogather_ms)}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_vals = cpu_baseline(wl)
             n = min(len(cpu_vals), W)
@@ -351,7 +454,21 @@ def main():
             assert torch.equal(gathered[:W], d_out), "all-gathered lnprob differs from the local block"
         dist.barrier()                       # rank 0's extra legs are done: leave together
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        return launch_ranks(args, argv)
+    if args.selftest_launcher:
+        if not under_launcher:
+            return launch_ranks(args, argv)        # also exercises the launcher with one rank
+        return selftest_rank()
+    return rank_main(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

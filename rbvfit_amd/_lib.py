@@ -37,6 +37,7 @@ SIGNATURES = {
     "vp_device_count": (C.c_int, []),
     "vp_ctx_create": (C.c_int, [C.POINTER(_ctx), C.c_int]),
     "vp_ctx_destroy": (C.c_int, [_ctx]),
+    "vp_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_long]),
     "vp_set_bounds": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
     "vp_add_instrument": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp,
                                     _ip, _ip, _ip, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(C.c_int)]),

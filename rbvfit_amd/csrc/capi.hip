@@ -19,6 +19,45 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Tuning / experiment knobs.  Defaults come from RBVFIT_AMD_* environment variables read ONCE, when the
+// context is created (never on the per-call path); vp_set_option changes them per context.
+struct Tuning {
+    int prep_rpw = 64;          // records per wave of prep_lines_kernel
+    int geom = -1;              // tile geometry: -1 by batch size, 0 two-pass tiles, 1 one-pass tiles
+    int finalize = -1;          // final reduction: -1 by batch size, 0 own launch, 1 ticket in the tile kernel
+    int walker = 0;             // walker_kernel (one launch per batch): -1 by batch size, 0 never, 1 whenever possible
+                                // (measured slower than the three launches at every batch size so far: off by default)
+    long walker_max_waves = 3072;    // ... by batch size: used while W x tiles <= this
+    long zerocopy_max = 1l << 20;    // bytes of theta up to which the host entry reads pinned host memory directly
+    int no_zerocopy = 0;
+    int no_multipole = 0;       // (read when an instrument is added)
+    int span = 0;               // evaluated pixels per tile, 0 = default (read when an instrument is added)
+    int waves = 0;              // waves per tile workgroup, 0 = default (read when an instrument is added)
+    long lds_pad = 0;           // extra LDS bytes per tile workgroup: occupancy experiments
+    int no_fused_accept = 0;    // device sampler: separate accept / propose launches
+};
+
+struct Knob { const char* name; const char* env; int is_long; size_t off; };
+#define VP_KNOB(field, envname, is_long) {#field, envname, is_long, offsetof(Tuning, field)}
+const Knob g_knobs[] = {
+    VP_KNOB(prep_rpw, "RBVFIT_AMD_PREP_RPW", 0), VP_KNOB(geom, "RBVFIT_AMD_GEOM", 0),
+    VP_KNOB(finalize, "RBVFIT_AMD_FINALIZE", 0), VP_KNOB(walker, "RBVFIT_AMD_WALKER", 0),
+    VP_KNOB(walker_max_waves, "RBVFIT_AMD_WALKER_MAX_WAVES", 1), VP_KNOB(zerocopy_max, "RBVFIT_AMD_ZEROCOPY_MAX", 1),
+    VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0),
+    VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
+    VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0),
+};
+void set_knob(Tuning& t, const Knob& k, long v) {
+    char* base = reinterpret_cast<char*>(&t) + k.off;
+    if (k.is_long) *reinterpret_cast<long*>(base) = v; else *reinterpret_cast<int*>(base) = (int)v;
+}
+Tuning tuning_from_env() {
+    Tuning t;
+    for (const Knob& k : g_knobs)
+        if (const char* e = getenv(k.env)) set_knob(t, k, *e ? atol(e) : 1);     // set but empty counts as 1
+    return t;
+}
+
 struct Instrument {
     vp::InstDev dev{};
     vp::InstDev dev_s{};         // same instrument, one-pass tiles: used for small batches (lnprob only)
@@ -40,8 +79,10 @@ struct Instrument {
 struct vp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::mutex mu;
+    mutable std::mutex mu;
     mutable std::string err;
+    Tuning tune;
+    size_t lds_limit = 65536;    // dynamic LDS a workgroup may ask for on this device
     int D = 0;
     double* d_lb = nullptr;
     double* d_ub = nullptr;
@@ -56,7 +97,6 @@ struct vp_ctx {
     double* d_partial = nullptr; // (capW, total_tiles)
     int* d_flags = nullptr;      // (capW)
     unsigned int* d_ticket = nullptr;  // (capW) arrival counters of the fused final reduction
-    unsigned long long* d_stamps = nullptr;   // diagnostic builds only
     int* d_genflag = nullptr;    // (capW) walkers with lines outside the fast domain (per instrument pass)
     std::vector<double> h_lb;    // host copy of the lower bounds
     int* d_tile_off = nullptr;   // 2 x (n_inst + 1): tile offsets of the full-size and of the one-pass geometry
@@ -217,12 +257,11 @@ size_t prof_mark(vp_ctx* c, hipStream_t s) {
 // (line records; the first one also applies the box prior and writes -inf rows) and a tile launch;
 // the last-arriving tile workgroup of each walker performs the final reduction.
 // Record preparation launch: one lane per record, 64 records per wave (fewer per wave measured no
-// faster even at 512 walkers x 4 lines; RBVFIT_AMD_PREP_RPW overrides for experiments).
+// faster even at 512 walkers x 4 lines; the prep_rpw knob overrides for experiments).
 static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_theta, int W, int do_flags, double* d_out,
                         int* genflag, hipStream_t s) {
     const long nline = (long)W * in.dev.L, ncl = (long)W * in.dev.NCm;
-    int rpw = 64;
-    if (const char* e = getenv("RBVFIT_AMD_PREP_RPW")) rpw = std::max(1, std::min(64, atoi(e)));
+    const int rpw = std::max(1, std::min(64, c->tune.prep_rpw));
     vp::PrepGrid g;
     g.rpw = rpw;
     g.nb_line = (int)((nline + rpw - 1) / rpw);
@@ -232,16 +271,51 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
                        in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g);
 }
 
+// walker_kernel: the whole batch in ONE launch (workgroup = walker, wave = tile).  Possible for a single
+// instrument with single-wave tiles, at most 16 of them, whose prior box keeps every line in the fast
+// domain; worth it while the batch is small enough that the prep and finalize launches (4-5 us each) and
+// the dispatch of thousands of one-wave workgroups matter -- large batches keep the one-wave workgroups,
+// which let the hardware refill single wave slots as tiles finish.
+size_t walker_lds_bytes(const Instrument& in) { return (size_t)in.dev.ntiles * in.lds_bytes + (in.dev.ntiles + 2) * sizeof(double); }
+
+bool walker_applies(const vp_ctx* c, int W) {
+    if (c->tune.walker == 0 || c->inst.size() != 1) return false;
+    const Instrument& in = c->inst[0];
+    if (in.nwaves != 1 || in.dev.ntiles > vp::WALKER_THREADS_MAX / 64) return false;
+    if (in.dev.method == VP_VOIGT_WOFZ && in.needs_generic) return false;
+    if (walker_lds_bytes(in) > c->lds_limit) return false;
+    return c->tune.walker == 1 || (long)W * in.dev.ntiles <= c->tune.walker_max_waves;
+}
+
+void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
+    const Instrument& in = c->inst[0];
+    vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, in.sum_logw, c->D, (int)(in.lds_bytes / sizeof(double))};
+    const dim3 grid(W), block(64 * in.dev.ntiles);
+    const size_t lds = walker_lds_bytes(in);
+    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false>), grid, block, lds, s, in.dev, in.lines, a);
+    else if (in.dev.NCm > 0) hipLaunchKernelGGL((vp::walker_kernel<0, true>), grid, block, lds, s, in.dev, in.lines, a);
+    else hipLaunchKernelGGL((vp::walker_kernel<0, false>), grid, block, lds, s, in.dev, in.lines, a);
+}
+
 int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
     int tile_off = 0;
     const bool prof = c->profiling;
     size_t m0 = prof ? prof_mark(c, s) : 0;
+    if (walker_applies(c, W)) {
+        launch_walker(c, W, d_theta, d_out, s);
+        if (prof) {
+            size_t m1 = prof_mark(c, s);
+            c->spans.push_back({m0, m1, 1});
+        }
+        HIP_TRY(c, hipGetLastError());
+        return VP_OK;
+    }
     // Geometry: a batch whose full-size tiles would leave most wave slots empty is cut into one-pass
     // tiles instead (twice the workgroups, half the per-wave latency): measured better up to 384
     // walkers x 12 tiles (30.2 vs 31.1 us), equal at 448, worse at 512 (256 CUs x 4 SIMDs x 6 waves =
     // 6144 slots).
     int sel = ((long)W * c->total_tiles_g[0] <= 4800) ? 1 : 0;
-    if (const char* e = getenv("RBVFIT_AMD_GEOM")) sel = atoi(e) ? 1 : 0;
+    if (c->tune.geom >= 0) sel = c->tune.geom ? 1 : 0;
     const int ntot = c->total_tiles_g[sel];
     // Final reduction (bit-identical either way, see tile_kernel): fused into the tile kernel -- the
     // last-arriving tile of a walker, by ticket -- while the batch leaves wave slots empty; a small launch of
@@ -249,10 +323,10 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     // every tile wave cost more than a launch.  Measured on C1 (us per pass, own launch / ticket): 256
     // walkers 26.5 / 26.7, 512: 32.3 / 33.0-33.9, 2048: 88.9 / 92.5, 8192: 314 / 329.
     int fmode = ((long)W * c->total_tiles_g[0] < 6144) ? 1 : 0;
-    if (const char* e = getenv("RBVFIT_AMD_FINALIZE")) fmode = atoi(e) ? 1 : 0;      // 0: own launch, 1: ticket
+    if (c->tune.finalize >= 0) fmode = c->tune.finalize ? 1 : 0;      // 0: own launch, 1: ticket
     const bool fused = fmode != 0;
     const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw,
-                               d_out, (int)c->inst.size(), ntot, fmode, c->d_stamps};
+                               d_out, (int)c->inst.size(), ntot, fmode};
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
@@ -297,8 +371,8 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     return VP_OK;
 }
 
+// (called with c->mu held)
 int check_batch_args(vp_ctx* c, int W, int D, const void* a, const void* b) {
-    if (!c) return VP_EINVAL;
     if (c->D <= 0) return fail(c, VP_ESTATE, "vp_set_bounds has not been called");
     if (c->inst.empty()) return fail(c, VP_ESTATE, "no instrument has been added");
     if (D != c->D) return fail(c, VP_EINVAL, "theta has D=" + std::to_string(D) + " but the context was set up with D=" + std::to_string(c->D));
@@ -332,13 +406,40 @@ int vp_ctx_create(vp_ctx** out, int device_id) {
     vp_ctx* c = new (std::nothrow) vp_ctx();
     if (!c) return fail(nullptr, VP_ENOMEM, "out of host memory");
     c->device = device_id;
+    c->tune = tuning_from_env();
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         std::string m = std::string("context creation failed: ") + hipGetErrorString(e);
         delete c;
         return fail(nullptr, VP_EHIP, m);
     }
+    // Dynamic LDS a workgroup may ask for: the device's per-workgroup limit (160 KiB on MI355X).  The
+    // tile and walker kernels are told they may use all of it (a no-op where the runtime does not need it).
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds_max > 0)
+        c->lds_limit = (size_t)lds_max;
+    for (const void* f : {(const void*)vp::walker_kernel<0, false>, (const void*)vp::walker_kernel<0, true>,
+                          (const void*)vp::walker_kernel<1, false>,
+                          (const void*)vp::tile_kernel<0, 0, false>, (const void*)vp::tile_kernel<0, 0, true>,
+                          (const void*)vp::tile_kernel<0, 1, false>, (const void*)vp::tile_kernel<0, 1, true>,
+                          (const void*)vp::tile_kernel<0, 2, false>, (const void*)vp::tile_kernel<0, 2, true>,
+                          (const void*)vp::tile_kernel<1, 0, false>, (const void*)vp::tile_kernel<1, 1, false>,
+                          (const void*)vp::tile_kernel<1, 2, false>})
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_limit);
+    (void)hipGetLastError();
     *out = c;
     return VP_OK;
+}
+
+int vp_set_option(vp_ctx* c, const char* name, long value) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!name) return fail(c, VP_EINVAL, "vp_set_option: NULL name");
+    for (const Knob& k : g_knobs)
+        if (std::strcmp(k.name, name) == 0) {
+            set_knob(c->tune, k, value);
+            return VP_OK;
+        }
+    return fail(c, VP_EINVAL, std::string("vp_set_option: unknown option '") + name + "'");
 }
 
 int vp_ctx_destroy(vp_ctx* c) {
@@ -437,7 +538,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         int e = l + 1;
         while (e < L && lambda0[e] == lambda0[l] && zfac[e] == zfac[l]) ++e;
         for (int k = l; k < e; ++k) cl_end[k] = e;
-        const bool enable = !getenv("RBVFIT_AMD_NO_MULTIPOLE");
+        const bool enable = !c->tune.no_multipole;
         // (two lines cost about as much as one 13-term expansion: only clusters of >= 3 pay off)
         if (enable && e - l >= 3 && e - l <= 64 && voigt_method == VP_VOIGT_WOFZ) {
             cl_mp[l] = (int)cl_first.size();
@@ -461,8 +562,8 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     // (K-1 re-evaluated pixels per tile) a small fraction.
     int nwaves = Kuse <= 33 ? 1 : Kuse <= 65 ? 2 : 4;
     int span = 2 * 64 * vp::RB * nwaves;                 // two register-blocked passes per wave
-    if (const char* sp = getenv("RBVFIT_AMD_SPAN")) span = atoi(sp);     // tuning experiments (multiple of 64)
-    if (const char* nw = getenv("RBVFIT_AMD_WAVES")) nwaves = atoi(nw);
+    if (c->tune.waves > 0) nwaves = std::min(4, c->tune.waves) == 3 ? 2 : std::min(4, c->tune.waves);   // tuning experiments: 1, 2 or 4
+    if (c->tune.span > 0) span = std::max(64, (c->tune.span / 64) * 64);                         // (multiple of 64)
     if (Kuse > 257) { span = std::min(8192, ((4 * Kuse + 63) / 64) * 64); nwaves = 4; }
     const int need = P + Kuse - 1;
     if (need < span) span = std::max(64, ((need + 63) / 64) * 64);
@@ -479,10 +580,16 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         }
     }
     in.lds_bytes = (size_t)(span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + ((Kuse + 7) & ~7) + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
+    if (in.lds_bytes + (size_t)std::max(0l, c->tune.lds_pad) > c->lds_limit) {
+        for (void* p : in.allocs) hipFree(p);
+        return fail(c, VP_EINVAL, "vp_add_instrument: a " + std::to_string(Kuse) + "-tap LSF with " + std::to_string(L) +
+                    " lines needs " + std::to_string(in.lds_bytes) + " B of LDS per tile workgroup, the device allows " +
+                    std::to_string(c->lds_limit));
+    }
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
     in.h_lambda0.assign(lambda0, lambda0 + L); in.h_gamma.assign(gamma, gamma + L); in.h_bidx.assign(b_idx, b_idx + L);
     analyse_generic(c, in);
-    if (const char* pad = getenv("RBVFIT_AMD_LDS_PAD")) in.lds_bytes += (size_t)atol(pad);   // occupancy experiments
+    if (c->tune.lds_pad > 0) in.lds_bytes += (size_t)c->tune.lds_pad;   // occupancy experiments
     c->inst.push_back(std::move(in));
     c->meta_dirty = true;
     if (inst_index) *inst_index = (int)c->inst.size() - 1;
@@ -505,10 +612,11 @@ int vp_update_spectrum(vp_ctx* c, int inst, const double* flux, const double* in
 }
 
 int vp_lnprob_batch_device(vp_ctx* c, int W, int D, const double* d_theta, double* d_out, void* hip_stream) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
     int rc = check_batch_args(c, W, D, d_theta, d_out);
     if (rc) return rc;
     if (W == 0) return VP_OK;
-    std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
@@ -516,19 +624,19 @@ int vp_lnprob_batch_device(vp_ctx* c, int W, int D, const double* d_theta, doubl
 }
 
 int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
     int rc = check_batch_args(c, W, D, theta, out);
     if (rc) return rc;
     if (W == 0) return VP_OK;
-    std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     const size_t tb = (size_t)W * D * sizeof(double), ob = (size_t)W * sizeof(double);
     if ((rc = ensure_pinned(c, tb + ob))) return rc;
     std::memcpy(c->h_pinned, theta, tb);
     double* h_out = c->h_pinned + (size_t)W * D;
-    size_t zc_max = (size_t)1 << 20;     // measured: 512 walkers x 6 parameters 50 us/call zero-copy vs 58 us with copies
-    if (const char* e = getenv("RBVFIT_AMD_ZEROCOPY_MAX")) zc_max = (size_t)atol(e);
-    if (tb <= zc_max && !getenv("RBVFIT_AMD_NO_ZEROCOPY")) {
+    // zerocopy_max defaults to 1 MiB; measured: 512 walkers x 6 parameters 50 us/call zero-copy vs 58 us with copies
+    if (tb <= (size_t)std::max(0l, c->tune.zerocopy_max) && !c->tune.no_zerocopy) {
         // up to 1 MiB of theta: the kernels read theta from / write lnprob to the pinned (host-coherent)
         // buffer directly over PCIe -- no H2D/D2H copy commands on the latency path
         double* dp = nullptr;
@@ -544,16 +652,10 @@ int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
     return VP_OK;
 }
 
-int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* d_theta, double* d_out, int convolved,
-                               void* hip_stream) {
-    int rc = check_batch_args(c, W, D, d_theta, d_out);
-    if (rc) return rc;
-    if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_batch: instrument index out of range");
-    if (W == 0) return VP_OK;
-    std::lock_guard<std::mutex> g(c->mu);
-    HIP_TRY(c, hipSetDevice(c->device));
+// (called with c->mu held) prep + tile launches that write the (W, P) model flux of one instrument
+static int enqueue_model_flux(vp_ctx* c, int inst, int W, const double* d_theta, double* d_out, int convolved, hipStream_t s) {
+    int rc;
     if ((rc = ensure_workspace(c, W))) return rc;
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const Instrument& in = c->inst[inst];
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;      // model_flux has no prior box: theta may be anything
     if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
@@ -571,33 +673,43 @@ int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* 
     return VP_OK;
 }
 
+int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* d_theta, double* d_out, int convolved,
+                               void* hip_stream) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    int rc = check_batch_args(c, W, D, d_theta, d_out);
+    if (rc) return rc;
+    if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_batch: instrument index out of range");
+    if (W == 0) return VP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return enqueue_model_flux(c, inst, W, d_theta, d_out, convolved, hip_stream ? (hipStream_t)hip_stream : c->stream);
+}
+
 int vp_model_flux_batch(vp_ctx* c, int inst, int W, int D, const double* theta, double* out, int convolved) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);          // held from staging theta to the copy-back: d_theta / d_scratch are the context's
     int rc = check_batch_args(c, W, D, theta, out);
     if (rc) return rc;
     if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_batch: instrument index out of range");
     if (W == 0) return VP_OK;
-    size_t P;
-    {
-        std::lock_guard<std::mutex> g(c->mu);
-        HIP_TRY(c, hipSetDevice(c->device));
-        if ((rc = ensure_workspace(c, W))) return rc;
-        P = c->inst[inst].dev.P;
-        if ((rc = ensure_scratch(c, (size_t)W * P * sizeof(double)))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    }
-    if ((rc = vp_model_flux_batch_device(c, inst, W, D, c->d_theta, c->d_scratch, convolved, c->stream))) return rc;
-    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, W))) return rc;
+    const size_t P = c->inst[inst].dev.P;
+    if ((rc = ensure_scratch(c, (size_t)W * P * sizeof(double)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = enqueue_model_flux(c, inst, W, c->d_theta, c->d_scratch, convolved, c->stream))) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, (size_t)W * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VP_OK;
 }
 
 int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* theta, double* out) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
     int rc = check_batch_args(c, W, D, theta, out);
     if (rc) return rc;
     if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_components: instrument index out of range");
     if (W == 0) return VP_OK;
-    std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     Instrument in = c->inst[inst];                 // local copy: line_sel is varied per launch
@@ -626,12 +738,13 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
 
 int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
                    uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
     int rc = check_batch_args(c, W, D, pos, lnprob);
     if (rc) return rc;
     if (W < 2 || (W & 1)) return fail(c, VP_EINVAL, "vp_stretch_run: the number of walkers must be even and >= 2");
     if (nsteps < 0 || !(a > 1.0)) return fail(c, VP_EINVAL, "vp_stretch_run: nsteps must be >= 0 and a > 1");
     if ((chain == nullptr) != (chain_lnprob == nullptr)) return fail(c, VP_EINVAL, "vp_stretch_run: chain and chain_lnprob go together");
-    std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     hipStream_t s = c->stream;
@@ -652,10 +765,21 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     int* d_nan = reinterpret_cast<int*>(d_nacc + W);
     HIP_TRY(c, hipMemcpyAsync(d_pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync(d_nacc, 0, (size_t)W * sizeof(long long) + sizeof(int), s));
-    if (have_lnprob) HIP_TRY(c, hipMemcpyAsync(d_lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, s));
-    else if ((rc = enqueue_lnprob(c, W, d_pos, d_lp, s))) return rc;
+    if (have_lnprob) {
+        for (int w = 0; w < W; ++w)
+            if (lnprob[w] != lnprob[w]) return fail(c, VP_ENAN, "vp_stretch_run: the initial lnprob holds NaN (Probability function returned NaN)");
+        HIP_TRY(c, hipMemcpyAsync(d_lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, s));
+    } else {
+        // a walker that starts at NaN would never move (log u < NaN is false) and the run would still report success
+        if ((rc = enqueue_lnprob(c, W, d_pos, d_lp, s))) return rc;
+        hipLaunchKernelGGL(vp::nan_flag_kernel, dim3((W + 255) / 256), dim3(256), 0, s, d_lp, W, d_nan);
+        int h_nan0 = 0;
+        HIP_TRY(c, hipMemcpyAsync(&h_nan0, d_nan, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (h_nan0) return fail(c, VP_ENAN, "vp_stretch_run: the initial lnprob holds NaN (Probability function returned NaN)");
+    }
     const int thr = 64;
-    const bool fuse = W <= 1024 && !getenv("RBVFIT_AMD_NO_FUSED_ACCEPT");   // accept + next proposal in one launch
+    const bool fuse = W <= 1024 && !c->tune.no_fused_accept;   // accept + next proposal in one launch
     const int wthr = ((W + 63) / 64) * 64;
     bool have_prop = false;                                   // is the proposal of the coming pass already enqueued?
     for (int done = 0; done < nsteps;) {
@@ -714,8 +838,8 @@ void vp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]
 
 int vp_voigt_h(vp_ctx* c, int na, const double* a, int nx, const double* x, double* out) {
     if (!c) return VP_EINVAL;
-    if (na <= 0 || nx <= 0 || !a || !x || !out) return fail(c, VP_EINVAL, "vp_voigt_h: empty or NULL input");
     std::lock_guard<std::mutex> g(c->mu);
+    if (na <= 0 || nx <= 0 || !a || !x || !out) return fail(c, VP_EINVAL, "vp_voigt_h: empty or NULL input");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t rec = (size_t)na * vp::LC_STRIDE, need = (rec + na + nx + (size_t)na * nx) * sizeof(double);
     int rc;
@@ -766,26 +890,23 @@ int vp_profile_read(vp_ctx* c, double* prep_ms, double* tile_ms, double* finaliz
     return VP_OK;
 }
 
-#ifdef VP_STAMP
-// diagnostic build only (scripts/stamps.py): allocate the stamp buffer for n workgroups / copy it back
-extern "C" int vp_debug_stamps_alloc(vp_ctx* c, int n) {
-    if (c->d_stamps) hipFree(c->d_stamps);
-    if (hipMalloc((void**)&c->d_stamps, (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return 2;
-    hipMemset(c->d_stamps, 0, (size_t)n * 8 * sizeof(unsigned long long));
-    return 0;
-}
-extern "C" int vp_debug_stamps_read(vp_ctx* c, int n, unsigned long long* out) {
-    hipDeviceSynchronize();
-    return hipMemcpy(out, c->d_stamps, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
-}
-#endif
 
 void* vp_ctx_stream(const vp_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-int vp_num_instruments(const vp_ctx* c) { return c ? (int)c->inst.size() : 0; }
-int vp_ndim(const vp_ctx* c) { return c ? c->D : 0; }
+int vp_num_instruments(const vp_ctx* c) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    return (int)c->inst.size();
+}
+int vp_ndim(const vp_ctx* c) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> g(c->mu);
+    return c->D;
+}
 int vp_instrument_pixels(const vp_ctx* c, int inst) {
-    if (!c || inst < 0 || inst >= (int)c->inst.size()) return -1;
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (inst < 0 || inst >= (int)c->inst.size()) return -1;
     return c->inst[inst].dev.P;
 }
 int vp_device_id(const vp_ctx* c) { return c ? c->device : -1; }

@@ -122,4 +122,10 @@ __global__ __launch_bounds__(1024) void stretch_accept_propose_kernel(
     stretch_propose(threadIdx.x, pos, D, nx.s0, nx.nS, nx.c0, nx.nC, a, seed, nx.step, nx.half, prop, zz);
 }
 
+// Flags a NaN in a lnprob vector (the initial state of a run: emcee and the host sampler raise on it).
+__global__ void nan_flag_kernel(const double* __restrict__ lp, int W, int* __restrict__ nanflag) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < W && lp[w] != lp[w]) atomicExch(nanflag, 1);
+}
+
 }  // namespace vp

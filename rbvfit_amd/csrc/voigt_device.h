@@ -32,7 +32,17 @@
 
 namespace vp {
 
-// ---- per-(walker,line) record written by prep_lines_kernel, read with scalar loads ------------
+// ---- per-(walker,line) record written by the record preparation, read with scalar loads -------
+// Records are READ through constant-address-space pointers (`rec_t`): a wave-uniform load from that
+// address space is always selected as a scalar load (s_load_*, fields land in SGPRs), also in
+// walker_kernel, whose own lanes wrote the records earlier in the same launch -- for a plain global
+// pointer the compiler falls back to vector loads as soon as the kernel contains a store that may
+// alias.  The hardware side of that hand-off (vector stores drained to L2, then scalar loads of lines
+// the scalar cache cannot hold yet) is described at walker_kernel.
+typedef const double __attribute__((address_space(4)))* rec_t;
+typedef const int __attribute__((address_space(4)))* rec_int_t;
+__device__ __forceinline__ rec_t as_rec(const double* p) { return (rec_t)reinterpret_cast<unsigned long long>(p); }
+__device__ __forceinline__ int rec_int(rec_t rec, int field, int k) { return ((rec_int_t)(rec + field))[k]; }
 constexpr int LC_STRIDE = 64;   // doubles per record (512 B, one record = 4 x 128-B lines)
 constexpr int NWING = 14;       // longest wing series (valid for |x| >= 8)
 constexpr int NCORE = 26;       // terms of the Gaussian sum (covers |x| < 7.2)
@@ -151,7 +161,7 @@ __device__ __forceinline__ double exp_neg_tab(double t, const double* __restrict
 //   x    = (freq - freq0) * (1/b_f)
 // Each quotient is the correctly rounded one except when the true quotient lies within ~1e-24
 // (relative) of a rounding boundary.
-__device__ __forceinline__ double faithful_x(double wave, double g, const double* __restrict__ rec) {
+__device__ __forceinline__ double faithful_x(double wave, double g, rec_t rec) {
     const double d = rec[LC_D], rd = rec[LC_RD], cfd = rec[LC_CFD];
     double q0 = wave * rd;
     double e = __builtin_fma(-q0, d, wave);
@@ -165,7 +175,7 @@ __device__ __forceinline__ double faithful_x(double wave, double g, const double
 
 // Wing optical depth of one line: s * Horner_M(K, s), K premultiplied by N f constant a/sqrt(pi).
 template <int M>
-__device__ __forceinline__ double wing_tau(double x, const double* __restrict__ K) {
+__device__ __forceinline__ double wing_tau(double x, rec_t K) {
     const double s = fast_rcp1(x * x);
     double acc = K[M - 1];
 #pragma unroll
@@ -326,7 +336,7 @@ __device__ __forceinline__ double core_taylor_H_lds(double x, double a, double e
 // Core H(a,x), |x| < 7.2, 0 <= a < 7:  Alg. 916 real part
 //   H = E [ (erfcx(a) - c a S1) cos(2xa) + c x sin(xa) sinc(xa) ] + E * sum_n tblc_n (e^{2hnx} + e^{-2hnx})
 // with E = exp(-x^2), tblc_n = 0.5 c a exp(-h^2n^2)/(h^2n^2+a^2).
-__device__ __forceinline__ double core_H(double x, const double* __restrict__ rec) {
+__device__ __forceinline__ double core_H(double x, rec_t rec) {
     const double ax = fabs(x);
     const double y = rec[LC_Y];
     const double E = exp(-ax * ax);
@@ -367,7 +377,7 @@ __device__ inline double cf_rew(double x, double y) {
 }
 
 // Fully generic H for lines outside the fast domain (mode != 0): per-element branches, slow, rare.
-__device__ inline double generic_H(double x, const double* __restrict__ rec, int mode) {
+__device__ inline double generic_H(double x, rec_t rec, int mode) {
     const double y = rec[LC_Y];
     const double ax = fabs(x);
     if (mode == 1) {

@@ -16,8 +16,11 @@
 //              last-arriving tile of a walker (agent-scope atomics) sums the partials in fixed order
 //              and writes lnprob = -0.5 (sum - sum log w)                      (vfit_mcmc.py:348-353)
 //              -- or, for batches that fill the wave slots, finalize_kernel does (one lane per walker)
-//   Two instances: GENERIC=false (no out-of-line generic Faddeeva, 77 VGPRs, 5 waves/SIMD by LDS) and
+//   Two instances: GENERIC=false (no out-of-line generic Faddeeva, 77 VGPRs, 6 waves/SIMD) and
 //   GENERIC=true (handles walkers flagged by prep; launched only when the prior box allows a > 0.1).
+//   walker_kernel       grid W x (64 x tiles) thr   ONE launch per batch for small single-instrument batches:
+//                       workgroup = walker, wave t = tile t (the same tile work), records formed in the
+//                       workgroup, tile sums reduced through LDS -- no prep launch, no ticket, no finalize launch
 //
 // HBM layout: spectra (wave, 1/wave, flux, inv_sigma2) are 4 dense fp64 arrays per instrument,
 // read coalesced (8 B/lane) once per (walker, tile) and shared by all walkers through L2/MALL;
@@ -52,7 +55,6 @@ struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of 
     int n_inst;
     int total_tiles;             // arrivals per walker over all instruments
     int mode;                    // 0: finalize_kernel sums; 1: the last-arriving tile of the walker does (ticket)
-    unsigned long long* stamps;  // diagnostic builds (-DVP_STAMP): 8 time stamps per workgroup, else unused
 };
 
 struct InstDev {
@@ -304,17 +306,16 @@ __global__ __launch_bounds__(64) void prep_h_kernel(const double* __restrict__ a
     rec[LC_A] = 0; rec[LC_B] = 0; rec[LC_D] = 1; rec[LC_RD] = 1; rec[LC_CFD] = 0; rec[LC_FREQ0] = 0; rec[LC_IBF] = 1;
 }
 
+
 struct PixelX {    // x of one pixel for one line, computed from the spectrum grid
     double wv, g;
-    __device__ __forceinline__ double cheap(const double* __restrict__ rec) const {
-        return __builtin_fma(rec[LC_A], g, -rec[LC_B]);
-    }
-    __device__ __forceinline__ double faithful(const double* __restrict__ rec) const { return faithful_x(wv, g, rec); }
+    __device__ __forceinline__ double cheap(rec_t rec) const { return __builtin_fma(rec[LC_A], g, -rec[LC_B]); }
+    __device__ __forceinline__ double faithful(rec_t rec) const { return faithful_x(wv, g, rec); }
 };
 struct DirectX {   // x given (test hook)
     double x;
-    __device__ __forceinline__ double cheap(const double* __restrict__) const { return x; }
-    __device__ __forceinline__ double faithful(const double* __restrict__) const { return x; }
+    __device__ __forceinline__ double cheap(rec_t) const { return x; }
+    __device__ __forceinline__ double faithful(rec_t) const { return x; }
 };
 
 #define VP_NONE_BELOW(xa, thr) (__ballot((xa) < (thr)) == 0ull)
@@ -322,11 +323,11 @@ struct DirectX {   // x given (test hook)
 // Optical depth of one line at one pixel; tier chosen per wavefront from the cheap x.
 // (Single-chunk form: used by the H test hook and by the cold path of the tile kernel.)
 template <class XP>
-__device__ __forceinline__ double line_tau_wofz(const XP& xp, const double* __restrict__ rec) {
-    const int mode = reinterpret_cast<const int*>(rec + LC_MODE)[0];
+__device__ __forceinline__ double line_tau_wofz(const XP& xp, rec_t rec) {
+    const int mode = rec_int(rec, LC_MODE, 0);
     const double xc = xp.cheap(rec);
     const double xa = fabs(xc);
-    const double* __restrict__ K = rec + LC_K0;
+    rec_t K = rec + LC_K0;
     if (mode == 0) {
         if (VP_NONE_BELOW(xa, 30.0)) {             // far wings: the 1-FMA x is accurate enough
             if (VP_NONE_BELOW(xa, 3000.0)) return wing_tau<2>(xc, K);
@@ -339,7 +340,7 @@ __device__ __forceinline__ double line_tau_wofz(const XP& xp, const double* __re
         if (VP_NONE_BELOW(xa, X_CORE)) return wing_tau<NWING>(xf, K);
         // line core: evaluated for every lane of the chunk (no divergence); lanes beyond the core
         // radius of a mixed chunk take the 14-term wing value instead
-        const int nodd = reinterpret_cast<const int*>(rec + LC_MODE)[1];
+        const int nodd = rec_int(rec, LC_MODE, 1);
         double r = rec[LC_T] * core_taylor_H(xf, rec[LC_Y], rec[LC_EA2], nodd);
         if (__ballot(xa >= X_CORE) != 0ull) {
             const double rw = wing_tau<NWING>(xf, K);
@@ -360,36 +361,35 @@ __device__ __forceinline__ double line_tau_wofz(const XP& xp, const double* __re
 // Cold path of the tile kernel: one 64-pixel chunk of one line that touches the line core (or a
 // line outside the fast domain).  Out of line on purpose: it keeps the hot loop's registers and
 // instruction footprint small.
-__device__ __attribute__((noinline)) double cold_line_tau(double wv, double g, const double* rec) {
+__device__ __attribute__((noinline)) double cold_line_tau(double wv, double g, rec_t rec) {
     // the pointer is wave-uniform but arrives in VGPRs: scalarise it so the record fields are
     // fetched with scalar loads (valid under any EXEC mask)
-    const unsigned long long pv = reinterpret_cast<unsigned long long>(rec);
+    const unsigned long long pv = (unsigned long long)rec;
     const unsigned int plo = __builtin_amdgcn_readfirstlane((unsigned int)pv);
     const unsigned int phi = __builtin_amdgcn_readfirstlane((unsigned int)(pv >> 32));
-    const double* __restrict__ urec = reinterpret_cast<const double*>(((unsigned long long)phi << 32) | plo);
+    rec_t urec = (rec_t)(((unsigned long long)phi << 32) | plo);
     PixelX xp{wv, g};
     return line_tau_wofz(xp, urec);
 }
 
 template <class XP>
-__device__ __forceinline__ double line_tau_fast(const XP& xp, const double* __restrict__ rec, const double* __restrict__ et) {
+__device__ __forceinline__ double line_tau_fast(const XP& xp, rec_t rec, const double* __restrict__ et) {
     const double xf = xp.faithful(rec);
     return rec[LC_T] * tepper_garcia_H(xf, rec[LC_Y], et);
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile kernel
+// tile work
 // ---------------------------------------------------------------------------------------------
-constexpr int TILE_THREADS_MAX = 256;   // 1, 2 or 4 waves per workgroup (span = 256 pixels per wave)
-#ifndef VP_RB
-#define VP_RB 3     // measured: RB=3 (91 VGPRs, 5 waves/SIMD) beats RB=2 (79, 6) and RB=4 (109, 4) by 3-5 %
-#endif
+constexpr int TILE_THREADS_MAX = 256;   // tile_kernel: 1, 2 or 4 waves per workgroup
+constexpr int WALKER_THREADS_MAX = 1024; // walker_kernel: one wave per tile, up to 16 tiles per walker
 constexpr int FL_PAD = 10;        // LDS doubles after a tile's flux that the zero-padded taps may read
-constexpr int RB = VP_RB;         // 64-pixel chunks per wave pass (register blocking / ILP)
+constexpr int RB = 3;             // 64-pixel chunks per wave pass (register blocking / ILP); measured: RB=3
+                                  // beats RB=2 and RB=4 by 3-5 %
 
 // s * Horner_M(K, s) for RB independent chunks with the same M; K wave-uniform (SGPR operands).
 template <int M>
-__device__ __forceinline__ void wing_rb(const double (&x)[RB], const double* __restrict__ K, double (&tau)[RB]) {
+__device__ __forceinline__ void wing_rb(const double (&x)[RB], rec_t K, double (&tau)[RB]) {
     double s[RB], acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) s[r] = fast_rcp1(x[r] * x[r]);
@@ -411,45 +411,68 @@ struct Eager {            // prefetched one line ahead: what the tier decision n
     double A, B;
     int mode;
 };
-__device__ __forceinline__ Eager load_eager(const double* __restrict__ rec) {
+__device__ __forceinline__ Eager load_eager(rec_t rec) {
     Eager e;
     e.A = rec[LC_A];
     e.B = rec[LC_B];
-    e.mode = reinterpret_cast<const int*>(rec + LC_MODE)[0];
+    e.mode = rec_int(rec, LC_MODE, 0);
     return e;
 }
 
-// GENERIC = false: the fast instance (no out-of-line generic Faddeeva, ~77 VGPRs); it skips walkers
-// flagged in `genflag`.  GENERIC = true: full instance, processes ONLY the flagged walkers.  Every
-// (walker, tile) is therefore handled by exactly one of the two launches.
-template <int METHOD, int OUT, bool GENERIC>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
-__global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const double* __restrict__ lc,
-                                                            const int* __restrict__ flags,
-                                                            double* __restrict__ out, int out_stride,
-                                                            int out_offset, FinalizeArgs F,
-                                                            const int* __restrict__ genflag) {
-    // LDS: fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | LSF taps (zero-padded to 8k) | exp table | per-chunk "line core" masks
-    extern __shared__ double fl[];
-    // walkers are the fast grid dimension and the (short) last tile comes last, so the tail of the
-    // launch is filled with the cheapest workgroups
-    const int t = blockIdx.y, w = blockIdx.x;
-#ifdef VP_STAMP
-    unsigned long long st0 = __builtin_amdgcn_s_memrealtime(), st1 = 0, st2 = 0, st3 = 0, st4 = 0;
-#endif
-    const int oob = (OUT == 0) ? flags[w] : 0;   // tested below, after the first loads are in flight
-    const int gen = genflag ? genflag[w] : 0;
+// Synchronisation among the threads that share one tile.  SOLO: the tile belongs to ONE wave of a
+// larger workgroup (walker_kernel) and must not wait for the others: the LDS operations of a wave
+// execute in program order, so only the compiler has to be kept from reordering them.
+template <bool SOLO>
+__device__ __forceinline__ void tile_sync() {
+    if (SOLO) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// What a tile's threads fetch before they need the line records (LSF tap, exp table entry, the first
+// pass's pixel data): issued first, so that a wave's start-up is one memory round trip instead of
+// four -- and, in walker_kernel, runs under the record preparation.
+struct TilePre { double tap, e2, g[RB], wv[RB]; };
+__device__ __forceinline__ TilePre tile_preload(const InstDev& I, int t, int tid) {
+    const int lane = tid & 63, wid = tid >> 6;
+    const int p0 = t * I.TP;
+    const int n_eval = min(p0 + I.TP, I.P) - p0 + I.K - 1;
+    const int q0 = p0 - I.halo_lo;
+    TilePre pre;
+    pre.tap = I.kflip[min(tid, I.K - 1)];
+    pre.e2 = g_exp2_64[tid & 63];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int i = min(wid * (64 * RB) + r * 64 + lane, n_eval - 1);
+        const int q = min(max(q0 + i, 0), I.P - 1);
+        pre.g[r] = I.ginv[q];
+        pre.wv[r] = I.wave[q];
+    }
+    return pre;
+}
+
+// One tile of one walker: tau -> exp -> LSF -> chi^2 (OUT = 0; returns this WAVE's partial sum, already
+// reduced over its lanes) or model flux written to `out` (OUT = 1 convolved, 2 unconvolved).
+// `nthreads` threads (tid = 0..nthreads-1, whole waves) share the LDS block `fl`:
+//   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | LSF taps (zero-padded to 8k) | exp table |
+//   per-chunk "line core" masks
+// GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
+// fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
+template <int METHOD, int OUT, bool GENERIC, bool SOLO>
+__device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int t, int w,
+                                            int tid, int nthreads, const TilePre& pre, double* __restrict__ out,
+                                            int out_stride) {
     const int p0 = t * I.TP;
     const int p1 = min(p0 + I.TP, I.P);
     const int nout = p1 - p0;
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
-#if defined(VP_ABLATE) && VP_ABLATE == 8
-    const double* __restrict__ lcw = lc;                // timing experiment: every walker reads walker 0's records
-#else
-    const double* __restrict__ lcw = lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE;
-#endif
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int TILE_THREADS = blockDim.x, nwaves = blockDim.x >> 6;
+    const int lane = tid & 63, wid = SOLO ? 0 : (tid >> 6);
+    const int TILE_THREADS = SOLO ? 64 : nthreads, nwaves = SOLO ? 1 : (nthreads >> 6);
     double* __restrict__ daw = fl + I.span + FL_PAD + 4;   // Dawson table for the line cores (16-B aligned)
     double* __restrict__ ktap = daw + DAW_LDS_DOUBLES; // LSF taps, read back as LDS broadcasts
     const int Kp = (I.K + 7) & ~7;                     // taps padded with zeros to whole groups of 8
@@ -457,40 +480,22 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(etab + EXP_LDS_DOUBLES);
     const int nwords = (I.L + 63) >> 6;                // 64 lines per mask word
     const int nchunks = (n_eval + 63) >> 6;
-    // Put every independent load of the prologue in flight before the first wait: LSF taps, exp table,
-    // the first pass's pixel data (the flag loads above are scalar).  A wave's start-up is then one
-    // memory round trip instead of four.
-    const double tap_pre = I.kflip[min((int)threadIdx.x, I.K - 1)];
-    const double exp_pre = g_exp2_64[threadIdx.x & 63];
-    double g_pre[RB], wv_pre[RB];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int i = min(wid * (64 * RB) + r * 64 + lane, n_eval - 1);
-        const int q = min(max(q0 + i, 0), I.P - 1);
-        g_pre[r] = I.ginv[q];
-        wv_pre[r] = I.wave[q];
-    }
-    if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
-    if (GENERIC ? (gen == 0) : (gen != 0)) return;   // the other launch owns this walker
-    if ((int)threadIdx.x < Kp) ktap[threadIdx.x] = (int)threadIdx.x < I.K ? tap_pre : 0.0;
-    for (int j = threadIdx.x + TILE_THREADS; j < Kp; j += TILE_THREADS) ktap[j] = j < I.K ? I.kflip[j] : 0.0;
-    if (threadIdx.x < FL_PAD) fl[n_eval + threadIdx.x] = 0.0;   // what the zero taps multiply must be finite
-    if (threadIdx.x < EXP_LDS_DOUBLES) etab[threadIdx.x] = exp_pre;
+    if (tid < Kp) ktap[tid] = tid < I.K ? pre.tap : 0.0;
+    for (int j = tid + TILE_THREADS; j < Kp; j += TILE_THREADS) ktap[j] = j < I.K ? I.kflip[j] : 0.0;
+    if (tid < FL_PAD) fl[n_eval + tid] = 0.0;   // what the zero taps multiply must be finite
+    if (tid < EXP_LDS_DOUBLES) etab[tid] = pre.e2;
 
-#ifdef VP_STAMP
-    st1 = __builtin_amdgcn_s_memrealtime();
-#endif
     // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
-    //      Each wave owns 256 consecutive evaluated pixels per pass (RB chunks of 64); lines are the
+    //      Each wave owns 3 x 64 consecutive evaluated pixels per pass (RB chunks); lines are the
     //      outer loop so that a line's constants are fetched once and feed RB independent
     //      evaluations.  Chunks that touch a line core (or a line outside the fast domain) are only
     //      flagged; their tau goes to LDS raw and phase B finishes them.
     bool wave_any = false;                  // did this wave flag any (chunk, line) for phase B?  (wave-uniform)
     for (int base = wid * (64 * RB); base < n_eval; base += TILE_THREADS * RB) {
         double g[RB], wv[RB], tau[RB];
-        if (base == wid * (64 * RB)) {                    // first pass: loaded in the prologue
+        if (base == wid * (64 * RB)) {                    // first pass: loaded by tile_preload
 #pragma unroll
-            for (int r = 0; r < RB; ++r) { g[r] = g_pre[r]; wv[r] = wv_pre[r]; tau[r] = 0.0; }
+            for (int r = 0; r < RB; ++r) { g[r] = pre.g[r]; wv[r] = pre.wv[r]; tau[r] = 0.0; }
         } else {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
@@ -509,18 +514,14 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 unsigned long long todo[RB];
 #pragma unroll
                 for (int r = 0; r < RB; ++r) todo[r] = 0ull;
-#if defined(VP_ABLATE) && VP_ABLATE == 9
-                const int l1 = l0;                    // timing experiment: no line is evaluated (masks stay empty)
-#else
                 const int l1 = min(I.L, l0 + 64);
-#endif
                 Eager nxt = load_eager(lcw + (size_t)l0 * LC_STRIDE);
                 for (int l = l0; l < l1; ++l) {
                     // far from a whole cluster of components?  one multipole evaluation replaces all of
                     // its member lines (only tried at the first line of a cluster that fits this block)
                     const int mp = (I.NCm > 0 && I.line_sel < 0) ? I.cl_mp[l] : -1;
                     if (mp >= 0 && I.cl_end[l] <= l1) {
-                        const double* __restrict__ mrec = lcw + (size_t)(I.L + mp) * LC_STRIDE;
+                        rec_t mrec = lcw + (size_t)(I.L + mp) * LC_STRIDE;
                         const double Ac = mrec[MP_A], Bc = mrec[MP_B], yfar = mrec[MP_YFAR];
                         double y[RB];
 #pragma unroll
@@ -550,11 +551,11 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                         nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
                         continue;
                     }
-                    const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
+                    rec_t rec = lcw + (size_t)l * LC_STRIDE;
                     nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);   // scalar prefetch of the next line
                     const unsigned long long bit = 1ull << (l - l0);
                     const double A = cur.A, B = cur.B;
-                    const double* __restrict__ K = rec + LC_K0;
+                    rec_t K = rec + LC_K0;
                     double x[RB];
 #pragma unroll
                     for (int r = 0; r < RB; ++r) x[r] = __builtin_fma(A, g[r], -B);
@@ -566,12 +567,6 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                     double xm = fabs(x[0]);
 #pragma unroll
                     for (int r = 1; r < RB; ++r) xm = fmin(xm, fabs(x[r]));
-#if defined(VP_ABLATE) && VP_ABLATE == 5
-                    { wing_rb<2>(x, K, tau); continue; }
-#endif
-#if defined(VP_ABLATE) && VP_ABLATE == 6
-                    { wing_rb<6>(x, K, tau); continue; }
-#endif
                     if (VP_NONE_BELOW(xm, 30.0)) {        // the 1-FMA x is accurate enough out here
                         if (VP_NONE_BELOW(xm, 100.0)) {
                             if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, K, tau);
@@ -591,12 +586,8 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                     // chunks get their 14-term wing value here (wave-uniform branches)
 #pragma unroll
                     for (int r = 0; r < RB; ++r) {
-#if defined(VP_ABLATE) && VP_ABLATE == 1
-                        if (true) tau[r] += wing_tau<NWING>(xf[r], K);
-#else
                         if (VP_NONE_BELOW(fabs(x[r]), X_CORE)) tau[r] += wing_tau<NWING>(xf[r], K);
                         else todo[r] |= bit;
-#endif
                     }
                 }
 #pragma unroll
@@ -610,7 +601,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
         } else if (METHOD == 1) {
             for (int l = 0; l < I.L; ++l) {
                 if (I.line_sel >= 0 && l != I.line_sel) continue;
-                const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
+                rec_t rec = lcw + (size_t)l * LC_STRIDE;
                 // Far from the line (every |x| >= 28, i.e. x^2 >= 784): G = exp(-x^2) underflows to exactly 0
                 // in double, so the reference's expression (voigt_approx.py:79-81) reduces to
                 //   H = (a/sqrt(pi)) * 1.5 / (x^2 (x^2+1)^2)      [its x^-6 wing, trap T9]
@@ -640,27 +631,21 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int i = base + r * 64 + lane;
-#if defined(VP_ABLATE) && VP_ABLATE == 3
-            if (i < n_eval) fl[i] = pending[r] ? tau[r] : 1.0 - tau[r];
-#else
-            if (i < n_eval) fl[i] = pending[r] ? tau[r] : exp_neg_tab(tau[r], etab);   // voigt_model.py:217
-#endif
+            // voigt_model.py:217; a NaN tau (NaN pixel, poisoned line) stays NaN as in the reference
+            if (i < n_eval) fl[i] = (pending[r] || tau[r] != tau[r]) ? tau[r] : exp_neg_tab(tau[r], etab);
         }
     }
-    __syncthreads();
+    tile_sync<SOLO>();
 
-#ifdef VP_STAMP
-    st2 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // ---- phase B: line cores.  The flagged chunks of the tile are dealt round-robin to the four
+    // ---- phase B: line cores.  The flagged chunks of the tile are dealt round-robin to the
     //      waves (balanced whatever their position), each chunk finished by one wave: core series
     //      for every lane (no divergence), 14-term wing value for lanes of a mixed chunk beyond the
     //      core radius, then exp.  Single instance of the core code keeps the hot loop's registers
     //      low.  All control flow here is wave-uniform, so lane-held records stay readable.
     if (METHOD == 0) {
-        // anything to do?  A single-wave workgroup knows from its own registers (and skips the whole
-        // phase, mask scan included: ~1 us of a 10 us tile without line cores); wider workgroups scan
-        // the masks every wave wrote to LDS.  Uniform over the workgroup either way.
+        // anything to do?  A single wave knows from its own registers (and skips the whole phase, mask
+        // scan included: ~1 us of a 10 us tile without line cores); wider workgroups scan the masks
+        // every wave wrote to LDS.  Uniform over the tile's threads either way.
         bool anyc = wave_any;
         if (nwaves > 1) {
             unsigned int anycore = 0u;
@@ -671,74 +656,67 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
             anyc = __ballot(anycore != 0u) != 0ull;
         }
         if (anyc) {
-            dawson_to_lds(daw, threadIdx.x, TILE_THREADS);   // staged only when some chunk needs the core series
-            __syncthreads();
-        int kth = 0;
-        for (int c = 0; c < nchunks; ++c) {
-            unsigned int any = 0u;
-            for (int wd = 0; wd < nwords; ++wd) {
-                const unsigned long long mw = cmask[c * nwords + wd];
-                any |= (unsigned int)mw | (unsigned int)(mw >> 32);
-            }
-            if (__builtin_amdgcn_readfirstlane(any) == 0u) continue;
-            if ((kth++ & (nwaves - 1)) != wid) continue;
-            const int i = c * 64 + lane;
-            const int ic = min(i, n_eval - 1);
-            const int q = min(max(q0 + ic, 0), I.P - 1);
-            const double gq = I.ginv[q], wq = I.wave[q];
-            double tau = fl[ic];
-            for (int wd = 0; wd < nwords; ++wd) {
-                unsigned long long m = cmask[c * nwords + wd];
-                {   // scalarise (mind the sign: readfirstlane returns int)
-                    const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)m);
-                    const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
-                    m = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
+            dawson_to_lds(daw, tid, TILE_THREADS);   // staged only when some chunk needs the core series
+            tile_sync<SOLO>();
+            int kth = 0;
+            for (int c = 0; c < nchunks; ++c) {
+                unsigned int any = 0u;
+                for (int wd = 0; wd < nwords; ++wd) {
+                    const unsigned long long mw = cmask[c * nwords + wd];
+                    any |= (unsigned int)mw | (unsigned int)(mw >> 32);
                 }
-                while (m) {
-                    const int l = (wd << 6) + __builtin_ctzll(m);
-                    m &= m - 1;
-                    const double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
-                    const int mode = reinterpret_cast<const int*>(rec + LC_MODE)[0];
-                    if (mode != 0) {
-                        if (GENERIC) tau += cold_line_tau(wq, gq, rec);
-                        else tau = __builtin_nan("");          // poisoned line (non-finite constants)
-                        continue;
+                if (__builtin_amdgcn_readfirstlane(any) == 0u) continue;
+                if ((kth++ & (nwaves - 1)) != wid) continue;
+                const int i = c * 64 + lane;
+                const int ic = min(i, n_eval - 1);
+                const int q = min(max(q0 + ic, 0), I.P - 1);
+                const double gq = I.ginv[q], wq = I.wave[q];
+                double tau = fl[ic];
+                for (int wd = 0; wd < nwords; ++wd) {
+                    unsigned long long m = cmask[c * nwords + wd];
+                    {   // scalarise (mind the sign: readfirstlane returns int)
+                        const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)m);
+                        const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
+                        m = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
                     }
-                    const double xf = faithful_x(wq, gq, rec);
-                    const double xa = fabs(xf);
-                    const int nodd = reinterpret_cast<const int*>(rec + LC_MODE)[1];
-                    double h = rec[LC_T] * core_taylor_H_lds(xf, rec[LC_Y], rec[LC_EA2], nodd, daw, etab);
-                    if (__ballot(xa >= X_CORE) != 0ull) {
-                        const double rw = wing_tau<NWING>(xf, rec + LC_K0);
-                        h = (xa >= X_CORE) ? rw : h;
+                    while (m) {
+                        const int l = (wd << 6) + __builtin_ctzll(m);
+                        m &= m - 1;
+                        rec_t rec = lcw + (size_t)l * LC_STRIDE;
+                        const int mode = rec_int(rec, LC_MODE, 0);
+                        if (mode != 0) {
+                            if (GENERIC) tau += cold_line_tau(wq, gq, rec);
+                            else tau = __builtin_nan("");          // poisoned line (non-finite constants)
+                            continue;
+                        }
+                        const double xf = faithful_x(wq, gq, rec);
+                        const double xa = fabs(xf);
+                        const int nodd = rec_int(rec, LC_MODE, 1);
+                        double h = rec[LC_T] * core_taylor_H_lds(xf, rec[LC_Y], rec[LC_EA2], nodd, daw, etab);
+                        if (__ballot(xa >= X_CORE) != 0ull) {
+                            const double rw = wing_tau<NWING>(xf, rec + LC_K0);
+                            h = (xa >= X_CORE) ? rw : h;
+                        }
+                        tau += h;
                     }
-                    tau += h;
                 }
+                if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg_tab(tau, etab);   // NaN survives (poisoned lines)
             }
-            if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg_tab(tau, etab);   // NaN survives (poisoned lines)
         }
-        }
-        __syncthreads();
+        tile_sync<SOLO>();
     }
 
-#ifdef VP_STAMP
-    st3 = __builtin_amdgcn_s_memrealtime();
-#endif
     // ---- LSF from LDS, chi^2 term, reduce ------------------------------------------------------
     //      Each lane produces TWO adjacent output pixels from a sliding window of the flux held in
     //      registers: per group of 8 taps it reads 10 consecutive doubles as five 16-byte LDS reads
     //      (lane stride 16 B: conflict-free) for 16 FMAs -- 5 B of LDS traffic per output and tap
     //      instead of 8 B with one output per lane.  Taps are LDS broadcasts, zero-padded to groups of
-    //      8; the flux is followed by FL_PAD zeros (the window reads at most 9 doubles past the last one).  Per output the taps are still accumulated in
-    //      ascending order, so the result is bit-identical to the plain loop.
+    //      8; the flux is followed by FL_PAD zeros (the window reads at most 9 doubles past the last
+    //      one).  Per output the taps are still accumulated in ascending order, so the result is
+    //      bit-identical to the plain loop.
     double acc = 0.0;
-#if !defined(VP_CONV_PLAIN)
     if (OUT != 2) {
-#if defined(VP_ABLATE) && VP_ABLATE == 2
-        const int kn = 8;
-#else
         const int kn = Kp;
-#endif
         constexpr int CG = 2;                                         // pixel pairs per lane and iteration (ILP)
         for (int ob = 0; ob < nout; ob += 2 * CG * TILE_THREADS) {
             int o0[CG];
@@ -746,7 +724,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
             double m0[CG], m1[CG];
 #pragma unroll
             for (int c = 0; c < CG; ++c) {
-                o0[c] = ob + c * 2 * TILE_THREADS + 2 * (int)threadIdx.x;     // even
+                o0[c] = ob + c * 2 * TILE_THREADS + 2 * tid;          // even
                 const int oc = min(o0[c], (nout - 1) & ~1);           // lanes past the end re-read the last pair
                 fw[c] = reinterpret_cast<const double2*>(fl + oc);
                 m0[c] = 0.0; m1[c] = 0.0;
@@ -790,64 +768,36 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 }
             }
         }
-    } else
-#endif
-    for (int ib = 0; ib < nout; ib += TILE_THREADS * RB) {
-        double m[RB];
-        int idx[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            idx[r] = ib + r * TILE_THREADS + threadIdx.x;
-            m[r] = 0.0;
-        }
-        if (OUT == 2) {
-#pragma unroll
-            for (int r = 0; r < RB; ++r) m[r] = fl[min(idx[r], nout - 1) + I.halo_lo];
-        } else {
-#if defined(VP_ABLATE) && VP_ABLATE == 2
-            const int kn = 1;
-#else
-            const int kn = Kp;                                    // zero taps: fma(0, finite, m) == m exactly
-#endif
-            const double* fb[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) fb[r] = fl + min(idx[r], nout - 1);
-            int j = 0;
-            for (; j + 8 <= kn; j += 8) {                         // 8 taps per base-address update
-                const double* __restrict__ kb = ktap + j;         // uniform address: LDS broadcasts
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double kj = kb[u];
-#pragma unroll
-                    for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fb[r][j + u], m[r]);
-                }
-            }
-            for (; j < kn; ++j) {
-                const double kj = ktap[j];
-#pragma unroll
-                for (int r = 0; r < RB; ++r) m[r] = __builtin_fma(kj, fb[r][j], m[r]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            if (idx[r] < nout) {
-                const int p = p0 + idx[r];
-                if (OUT == 0) {
-                    const double d = I.flux[p] - m[r];
-                    acc = __builtin_fma(d * d, I.w[p], acc);      // (flux-model)^2 * inv_sigma2
-                } else {
-                    out[(size_t)w * out_stride + p] = m[r];
-                }
-            }
-        }
+    } else {
+        for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }
-#ifdef VP_STAMP
-    st4 = __builtin_amdgcn_s_memrealtime();
-#endif
+    return (OUT == 0) ? wave_sum(acc) : 0.0;
+}
+
+// Tile kernel: grid (W, tiles) x 64/128/256 threads, workgroup = walker x pixel tile; records come from a
+// prep_lines_kernel launch.  GENERIC = false skips walkers flagged in `genflag`, GENERIC = true processes
+// ONLY the flagged walkers: every (walker, tile) is handled by exactly one of the two launches.
+template <int METHOD, int OUT, bool GENERIC>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
+__global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const double* __restrict__ lc,
+                                                            const int* __restrict__ flags,
+                                                            double* __restrict__ out, int out_stride,
+                                                            int out_offset, FinalizeArgs F,
+                                                            const int* __restrict__ genflag) {
+    extern __shared__ double fl[];
+    // walkers are the fast grid dimension and the (short) last tile comes last, so the tail of the
+    // launch is filled with the cheapest workgroups
+    const int t = blockIdx.y, w = blockIdx.x;
+    const int oob = (OUT == 0) ? flags[w] : 0;   // tested below, after the first loads are in flight
+    const int gen = genflag ? genflag[w] : 0;
+    const TilePre pre = tile_preload(I, t, threadIdx.x);
+    if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
+    if (GENERIC ? (gen == 0) : (gen != 0)) return;   // the other launch owns this walker
+    rec_t lcw = as_rec(lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE);
+    const double wsum = tile_work<METHOD, OUT, GENERIC, false>(I, lcw, fl, t, w, threadIdx.x, blockDim.x, pre, out, out_stride);
     if (OUT == 0) {
-        acc = wave_sum(acc);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
         double* red = fl + I.span + FL_PAD;
-        if (lane == 0) red[wid] = acc;
+        if (lane == 0) red[wid] = wsum;
         __syncthreads();
         if (threadIdx.x == 0) {
             double tile_sum = red[0];
@@ -866,9 +816,6 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 return;
             }
             __hip_atomic_store(row + myslot, tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if defined(VP_ABLATE) && VP_ABLATE == 4
-            return;
-#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned int ticket = __hip_atomic_fetch_add(F.ticket + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ticket == (unsigned int)(F.total_tiles - 1)) {
@@ -882,13 +829,138 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                 F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
                 __hip_atomic_store(F.ticket + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-#ifdef VP_STAMP
-            if (F.stamps) {     // diagnostic only: wall-clock stamps (100 MHz) of this workgroup's phases
-                unsigned long long* sp = F.stamps + ((size_t)t * gridDim.x + w) * 8;
-                sp[0] = st0; sp[1] = st1; sp[2] = st2; sp[3] = st3; sp[4] = st4; sp[5] = __builtin_amdgcn_s_memrealtime();
-            }
-#endif
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// walker kernel: the whole lnprob of one walker in ONE workgroup, one launch per batch
+// ---------------------------------------------------------------------------------------------
+// Records of up to four lines by the 64 lanes of a wave: lane = 16 j + slot, j = line within the
+// group; slot m < 14 forms the wing coefficient K_m (its Horner polynomial in a^2 with per-lane
+// coefficients -- the same operations in the same order as fill_record, so the record is bit-identical
+// to prep_lines_kernel's), slots 14 and 15 store the scalars.  ~100 instructions per wave instead of
+// ~350 per record lane: this sits on the critical path of the walker's workgroup.
+__device__ __forceinline__ void prep_record_lanes(const double* __restrict__ th, const LinesDev& T, int l0,
+                                                  double* __restrict__ lcw, int lane) {
+    const int j = lane >> 4, slot = lane & 15, l = l0 + j;
+    if (l >= T.L) return;
+    const LineScalars s = line_scalars(th, T, l);
+    const bool xok = (fabs(s.Ax) <= 1.79e308) && (fabs(s.Bx) <= 1.79e308);
+    const double Tl = xok ? s.Tl : __builtin_nan(""), a = s.a;
+    double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
+    if (slot < NWING) {
+        const double a2 = a * a;
+        const double pref = Tl * (a * INV_SQRT_PI);
+        double cm = 0.0;
+#pragma unroll 7                                       // (7 coefficient loads in flight at a time: registers)
+        for (int i = NWING - 1; i >= 0; --i) {
+            const double c = g_wing.c[slot][i];        // (zero above the diagonal; not used there)
+            cm = (i <= slot) ? __builtin_fma(cm, a2, c) : cm;
+        }
+        rec[LC_K0 + slot] = pref * cm;
+    } else if (slot == 14) {
+        rec[LC_A] = s.Ax;
+        rec[LC_B] = s.Bx;
+        rec[LC_D] = s.d;
+        rec[LC_RD] = 1.0 / s.d;               // must be the correctly rounded reciprocal (faithful_x)
+        rec[LC_CFD] = s.cfd;
+        rec[LC_FREQ0] = s.freq0;
+        rec[LC_IBF] = s.ibf;
+    } else {
+        int mode = 0;
+        if (!(a >= 0.0) || !(a < 7.0)) mode = 2;
+        else if (a > 0.1) mode = 1;
+        if (!(fabs(a) <= 1.79e308) || !(fabs(Tl) <= 1.79e308)) mode = 3;
+        const double a2 = a * a;
+        rec[LC_T] = Tl;
+        rec[LC_Y] = a;
+        rec[LC_ACOS] = 0.0;                   // (the Alg. 916 table of mode 1 is only read by the GENERIC tile kernel)
+        reinterpret_cast<int*>(rec + LC_MODE)[0] = mode;
+        reinterpret_cast<int*>(rec + LC_MODE)[1] = core_terms(a);
+        // exp(a^2) by its Taylor terms as in fill_record (mode 0: a <= 0.1); other modes never read it here
+        rec[LC_EA2] = 1.0 + a2 * (1.0 + a2 * (0.5 + a2 * (1.0 / 6 + a2 * (1.0 / 24))));
+    }
+}
+
+struct WalkerArgs {
+    const double* theta;   // (W, D)
+    const double* lb;      // (D) box prior (vfit_mcmc.py:291-295)
+    const double* ub;
+    double* lc;            // (W, L + NCm, LC_STRIDE) record workspace
+    double* lnprob;        // (W)
+    double sum_logw;       // sum of log inv_sigma2 of the instrument
+    int D;
+    int wave_lds;          // LDS doubles per wave (= per tile)
+};
+
+// grid = W workgroups, block = 64 x ntiles threads (ntiles <= 16): wave t owns tile t of the walker and
+// runs tile_work exactly as a single-wave tile_kernel workgroup would (own LDS block, no barrier with
+// its siblings), so per-tile results -- and, with the same summation order, lnprob -- are bit-identical to
+// the prep + tile + finalize launches.  What the workgroup adds:
+//   1. the walker's records (prep_lines_kernel's work) are formed ONCE per walker by its first waves
+//      while the others already fetch their pixels; they go to the record workspace in HBM/L2 with
+//      plain vector stores, every storing wave drains them (s_waitcnt vmcnt(0): the write-through L1
+//      has handed them to L2), then ONE workgroup barrier, after which all waves read them with scalar
+//      loads.  The scalar cache cannot hold a stale copy: it is invalidated at every kernel start and
+//      nothing reads a walker's record lines before this barrier (records are 512-B aligned, scalar
+//      cache lines 64 B, so no neighbour's read touches them either);
+//   2. the box prior (-inf without evaluating the model) by one wave, through an LDS flag;
+//   3. the final reduction: per-tile sums meet in LDS behind a second barrier and thread 0 adds them in
+//      tile order -- no ticket, no atomics, no finalize launch.
+// Used for single-instrument contexts whose prior box keeps every line in the fast domain, for batches
+// small enough that launch overheads matter (capi.hip: enqueue_lnprob).
+template <int METHOD, bool CLUSTERS>   // CLUSTERS: the instrument has multipole cluster records (their preparation needs
+                                       // more registers than the tile work and spills to scratch; kept out of the
+                                       // plain instance)
+#ifndef VP_WALKER_WPE
+#define VP_WALKER_WPE 6
+#endif
+__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A) {
+    extern __shared__ double smem[];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler knows it: the tile
+                                                                   // geometry stays in SGPRs as in tile_kernel
+    double* __restrict__ fl = smem + (size_t)wid * A.wave_lds;
+    double* __restrict__ red = smem + (size_t)nw * A.wave_lds;      // nw tile sums, then the prior flag
+    const int nrec = T.L + T.NCm;
+    double* __restrict__ lcw = A.lc + (size_t)w * nrec * LC_STRIDE;
+    const double* __restrict__ th = A.theta + (size_t)w * A.D;
+    const int ngrp = (T.L + 3) >> 2, ncl = CLUSTERS ? ((T.NCm + 63) >> 6) : 0;
+    const int ntask = 1 + ngrp + ncl;              // task 0: box prior; then line groups; then cluster records
+    for (int task = wid; task < ntask; task += nw) {
+        if (task == 0) {
+            int oob = 0;
+            for (int d = lane; d < A.D; d += 64) oob |= (th[d] < A.lb[d]) || (th[d] > A.ub[d]);
+            const bool any = __ballot(oob != 0) != 0ull;
+            if (lane == 0) red[nw] = any ? 1.0 : 0.0;
+        } else if (task <= ngrp) {
+            prep_record_lanes(th, T, (task - 1) * 4, lcw, lane);
+        } else if (CLUSTERS) {
+            const int k = (task - 1 - ngrp) * 64 + lane;
+            if (k < T.NCm) prep_cluster(th, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
+        }
+    }
+    const TilePre pre = tile_preload(I, wid, lane);     // in flight while the stores drain
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (red[nw] != 0.0) {                          // out-of-bounds walker: the model is not evaluated
+        if (tid == 0) A.lnprob[w] = -__builtin_inf();
+        return;
+    }
+    // the record pointer is re-made behind the barrier through an opaque scalar move, so no record load
+    // can be scheduled above it
+    unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
+    const double wsum = tile_work<METHOD, 0, false, true>(I, (rec_t)pq, fl, wid, w, lane, 64, pre, nullptr, 0);
+    if (lane == 0) red[wid] = wsum;
+    __syncthreads();
+    if (tid == 0) {
+        double sk = 0.0;
+        for (int k = 0; k < nw; ++k) sk += red[k];
+        double total = 0.0;
+        total += -0.5 * (sk - A.sum_logw);         // vfit_mcmc.py:309-311
+        A.lnprob[w] = 0.0 + total;                 // lp + lnlike (vfit_mcmc.py:353)
     }
 }
 
@@ -923,7 +995,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(double* __restrict__ parti
 // Test hook: H(a_i, x_j) with the production tier logic (wave = 64 consecutive x_j of one a_i).
 __global__ __launch_bounds__(256) void voigt_h_kernel(const double* __restrict__ lc, const double* __restrict__ x,
                                                       int nx, double* __restrict__ out) {
-    const double* __restrict__ rec = lc + (size_t)blockIdx.y * LC_STRIDE;
+    rec_t rec = as_rec(lc + (size_t)blockIdx.y * LC_STRIDE);
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nx) return;
     DirectX xp{x[j]};

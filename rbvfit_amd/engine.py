@@ -76,6 +76,12 @@ class Engine:
         L.check(self._lib, self._ctx, rc)
 
     # -- setup ------------------------------------------------------------------------------
+    def set_option(self, name: str, value: int):
+        """Tuning knob of this context (``vp_set_option``): "geom", "finalize", "walker", ...; the
+        RBVFIT_AMD_<NAME> environment variables only give the defaults, read when the context is made."""
+        self._guard()
+        self._check(self._lib.vp_set_option(self._ctx, str(name).encode(), int(value)))
+
     def set_bounds(self, lb, ub):
         self._guard()
         lb, ub = _f64(lb).ravel(), _f64(ub).ravel()

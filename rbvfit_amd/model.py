@@ -126,12 +126,15 @@ class VoigtModel:
     """Single-instrument model description.  ``FWHM`` is in pixels, as a string or float, or None
     for no LSF; ``kernel_taps`` supplies a tabulated LSF (the reference's 'COS' / CustomKernel
     branch -> normalising 'extend' convolution).  ``normalize_kernel`` selects whether the Gaussian
-    taps are sum-normalised (astropy >= 5) or raw samples (astropy 4.x, the version the golden
-    fixtures were made with)."""
+    taps are sum-normalised -- what ``Gaussian1DKernel(...).array`` holds under the astropy the
+    reference declares (>= 5.3.3, setup.cfg:30-37), hence the default -- or raw samples (astropy 4.x:
+    the version the golden fixtures and the SURVEY anchors were made with; tests and the synthetic
+    workloads pass ``normalize_kernel=False`` explicitly).  For FWHM '6.5' the two differ by
+    sum(taps) = 1 - 2.8e-5 on every pixel (trap T2)."""
 
     def __init__(self, config: FitConfiguration, FWHM: Union[str, float, None] = "6.5",
                  voigt_method: str = "wofz", kernel_taps: Optional[Sequence[float]] = None,
-                 normalize_kernel: bool = False):
+                 normalize_kernel: bool = True):
         if voigt_method not in ("wofz", "fast"):
             raise ValueError(f"voigt_method must be one of ('wofz', 'fast'), got '{voigt_method}'")
         self.voigt_method = voigt_method

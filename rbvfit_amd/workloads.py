@@ -104,7 +104,8 @@ def make_workload(name: str, walkers: Optional[int] = None, device_id: int = 0, 
     tables, pix, spectra = [], [], []
     for iname, lo, hi, P, fwhm, tabulated in insts:
         P = int(pixels) if pixels else P
-        model = VoigtModel(cfg, FWHM=fwhm, kernel_taps=cos_like_kernel() if tabulated else None)
+        # raw (astropy-4.x) Gaussian taps, as in the golden fixtures and the SURVEY 8(a) anchors
+        model = VoigtModel(cfg, FWHM=fwhm, kernel_taps=cos_like_kernel() if tabulated else None, normalize_kernel=False)
         data = model.compile().data
         wave = np.linspace(lo, hi, P)
         err = np.full(P, 0.05)

@@ -143,3 +143,39 @@ def test_two_rank_gloo_pipelined_gather_and_islands():
     assert np.array_equal(l0, np.concatenate([ownl0, ownl1], axis=1))
     assert not np.array_equal(own0, own1)                       # different seeds per island
     assert m0.shape == (2, thetas.shape[1])
+
+
+# ---- bench.py's own N-rank launcher (python bench.py --gpus N typed directly) ------------------
+@pytest.mark.timeout(300)
+def test_bench_launcher_starts_its_own_ranks_over_gloo():
+    """`bench.py --gpus 2 --selftest-launcher`: the parent spawns 2 ranks through
+    torch.distributed.run (fresh child interpreters), they rendezvous on 127.0.0.1, run the
+    barrier / all-gather / max-reduce of the timed loop over gloo, and rank 0's JSON line is relayed."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"selftest": "launcher", "n_ranks": 2, "backend": "gloo", "ok": True}
+
+
+@pytest.mark.timeout(120)
+def test_bench_without_enough_gpus_fails_cleanly():
+    """On a box with fewer GPUs than --gpus the launcher says so (exit 2), before starting anything."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has 2 GPUs")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"],
+                       capture_output=True, text=True, env=env, timeout=100)
+    assert r.returncode == 2
+    assert "needs 2 GPUs" in r.stderr and r.stdout.strip() == ""

@@ -79,16 +79,18 @@ def test_random_configuration(seed):
         e.set_bounds(lb, ub)
         e.add_instrument(wave, flux, inst.inv_sigma2, inst.log_inv_sigma2, **data.engine_kwargs())
         got = e.lnprob(thetas)
-        os.environ["RBVFIT_AMD_GEOM"] = "0"              # the two-pass tile geometry and the separate final
-        os.environ["RBVFIT_AMD_FINALIZE"] = "0"          # reduction (large batches) as well
-        try:
-            got_big = e.lnprob(thetas)
-        finally:
-            del os.environ["RBVFIT_AMD_GEOM"], os.environ["RBVFIT_AMD_FINALIZE"]
+        for k, v in (("walker", 0), ("geom", 0), ("finalize", 0)):   # the two-pass tile geometry and the separate
+            e.set_option(k, v)                                         # final reduction (large batches) as well
+        got_big = e.lnprob(thetas)
+        e.set_option("walker", 1)                                      # and the one-launch walker kernel where it applies
+        got_walker = e.lnprob(thetas)
+        for k in ("walker", "geom", "finalize"):
+            e.set_option(k, -1)
         fl = e.model_flux(0, thetas[:3])
         un = e.model_flux(0, thetas[:2], convolved=False)
     np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     np.testing.assert_allclose(got_big, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    np.testing.assert_array_equal(got_walker, got_big)     # same tiles, same summation order: bit-identical
     for i in range(3):
         np.testing.assert_allclose(fl[i], vo.model_flux(od, thetas[i], wave), rtol=0, atol=FLUX_ATOL)
     for i in range(2):

@@ -15,15 +15,20 @@ def oracle():
     return vo
 
 
-# tile geometry (by batch size / two-pass "0" / one-pass "1") x final reduction (own launch "f0" / ticket "f1")
-@pytest.mark.parametrize("geom", ["auto", "0-f0", "0-f1", "1-f0", "1-f1"])
+# launch structure: "auto" (by batch size), "walker" (one launch, workgroup = walker, wherever it applies), or
+# prep + tile (+ finalize) launches with tile geometry two-pass "0" / one-pass "1" x final reduction own launch
+# "f0" / ticket "f1"
+@pytest.mark.parametrize("geom", ["auto", "walker", "0-f0", "0-f1", "1-f0", "1-f1"])
 @pytest.mark.parametrize("name", golden_cases())
-def test_lnprob_matches_golden(name, geom, monkeypatch):
+def test_lnprob_matches_golden(name, geom):
     z = load_golden(name)
-    if geom != "auto":
-        monkeypatch.setenv("RBVFIT_AMD_GEOM", geom[0])
-        monkeypatch.setenv("RBVFIT_AMD_FINALIZE", geom[-1])
     with engine_from_fixture(z) as eng:
+        if geom == "walker":
+            eng.set_option("walker", 1)
+        elif geom != "auto":
+            eng.set_option("walker", 0)
+            eng.set_option("geom", int(geom[0]))
+            eng.set_option("finalize", int(geom[-1]))
         got = eng.lnprob(z["thetas"])
     ref = z["lnprob"]
     assert np.array_equal(np.isneginf(got), np.isneginf(ref))
@@ -123,6 +128,57 @@ def test_context_usable_from_other_threads():
         assert not errors
         for k in range(4):
             assert np.array_equal(results[k], ref[k::4], equal_nan=True)
+    finally:
+        eng.close()
+
+
+def test_four_threads_mixing_every_entry_point():
+    """One context hammered by four threads that mix the host entries: lnprob (zero-copy and copy paths),
+    model_flux (stages theta in the context's d_theta and the flux in its scratch buffer), per-line
+    components, the Faddeeva test hook (re-allocates the scratch) and the device sampler (re-allocates it
+    again).  Every entry holds the context mutex from argument check to copy-back, so each result must be
+    exactly what the same call returns on a quiet context."""
+    import threading
+    z = load_golden("c0_mgii")
+    eng = engine_from_fixture(z)
+    try:
+        th = z["thetas"]
+        big = np.tile(th, (1 + (1 << 20) // (th.size * 8), 1))          # > 1 MiB of theta: the H2D-copy path of lnprob
+        ref = dict(lnp=eng.lnprob(th), lnp_big=eng.lnprob(big), flux=eng.model_flux(0, th[:6]),
+                   raw=eng.model_flux(0, th[6:9], convolved=False), comp=eng.model_flux_components(0, th[:2], 4),
+                   h=eng.voigt_h(np.array([1e-4, 3e-3]), np.linspace(-40, 40, 4001)),
+                   mc=eng.stretch_run(th[:16], 5, seed=3))
+        errors = []
+
+        def work(k):
+            try:
+                for it in range(6):
+                    order = [(k + it + j) % 7 for j in range(7)]
+                    for what in order:
+                        if what == 0:
+                            assert np.array_equal(eng.lnprob(th), ref["lnp"], equal_nan=True)
+                        elif what == 1:
+                            assert np.array_equal(eng.model_flux(0, th[:6]), ref["flux"])
+                        elif what == 2:
+                            assert np.array_equal(eng.model_flux(0, th[6:9], convolved=False), ref["raw"])
+                        elif what == 3:
+                            assert np.array_equal(eng.model_flux_components(0, th[:2], 4), ref["comp"])
+                        elif what == 4:
+                            assert np.array_equal(eng.voigt_h(np.array([1e-4, 3e-3]), np.linspace(-40, 40, 4001)), ref["h"])
+                        elif what == 5:
+                            got = eng.stretch_run(th[:16], 5, seed=3)
+                            assert all(np.array_equal(g, r) for g, r in zip(got, ref["mc"]))
+                        else:
+                            assert np.array_equal(eng.lnprob(big), ref["lnp_big"], equal_nan=True)
+            except BaseException as e:                          # pragma: no cover
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors[:3]
     finally:
         eng.close()
 

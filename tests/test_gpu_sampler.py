@@ -42,12 +42,9 @@ def test_runs_are_reproducible_and_splittable():
     np.testing.assert_array_equal(h2[4], a[4])
     c = eng.stretch_run(p0, 20, seed=12)
     assert not np.array_equal(c[2], a[2])
-    import os
-    os.environ["RBVFIT_AMD_NO_FUSED_ACCEPT"] = "1"            # separate accept / propose launches: same draws
-    try:
-        u = eng.stretch_run(p0, 20, seed=11)
-    finally:
-        del os.environ["RBVFIT_AMD_NO_FUSED_ACCEPT"]
+    eng.set_option("no_fused_accept", 1)                     # separate accept / propose launches: same draws
+    u = eng.stretch_run(p0, 20, seed=11)
+    eng.set_option("no_fused_accept", 0)
     np.testing.assert_array_equal(u[2], a[2]); np.testing.assert_array_equal(u[4], a[4])
     nochain = eng.stretch_run(p0, 20, seed=11, store_chain=False)
     assert nochain[2] is None
@@ -166,3 +163,89 @@ def test_device_sampler_multi_instrument_and_large_ensembles():
     np.testing.assert_array_equal(clp[-1], wl.engine.lnprob(chain[-1]))
     full = np.concatenate([wl.thetas[None], chain])
     np.testing.assert_array_equal(np.any(full[1:] != full[:-1], axis=2).sum(axis=0), nacc)
+
+
+# ---- independent host replay of vp_stretch_run (propose / accept kernels, csrc/sampler_kernels.h) ----------
+def _philox_np(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 over arrays of counters (numpy uint64 arithmetic; same function as tests/test_host_logic.py's
+    scalar restatement, which is pinned by the Random123 known-answer vectors)."""
+    M0, M1, W0, W1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85, np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) for c in np.broadcast_arrays(c0, c1, c2, c3))
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0), p1 & mask, (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1), p0 & mask
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def _u01(hi, lo):
+    return (((hi << np.uint64(32)) | lo) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _draw(seed, step, half, walkers, purpose):
+    """counter layout of sampler_kernels.h::draw: (walker, step low, step high | half << 31, purpose), key = seed."""
+    return _philox_np(walkers, step & 0xFFFFFFFF, (step >> 32) | (half << 31), purpose, seed & 0xFFFFFFFF, seed >> 32)
+
+
+def _replay_stretch(lnprob, p0, nsteps, a, seed, step0=0):
+    """The reference's emcee stretch move (vfit_mcmc.py:408-423, 536-540) as vp_stretch_run performs it, in NumPy:
+    red-blue halves, z = ((a-1)u+1)^2/a, partner j = floor(u2 nC), Y = X_j - (X_j - X_k) z, accept when
+    ln u < (D-1) ln z + lnprob(Y) - lnprob(X).  Only lnprob comes from the engine."""
+    pos = np.array(p0, dtype=np.float64)
+    W, D = pos.shape
+    half = W // 2
+    lp = lnprob(pos)
+    nacc = np.zeros(W, dtype=np.int64)
+    chain, clp = np.empty((nsteps, W, D)), np.empty((nsteps, W))
+    for it in range(nsteps):
+        step = step0 + it
+        for h in (0, 1):
+            s0, c0 = (half, 0) if h else (0, half)
+            wk = np.arange(s0, s0 + half)
+            r = _draw(seed, step, h, wk, 0)
+            u1, u2 = _u01(r[0], r[1]), _u01(r[2], r[3])
+            t = (a - 1.0) * u1 + 1.0
+            z = t * t / a
+            j = np.minimum((u2 * float(half)).astype(np.int64), half - 1)
+            x, c = pos[wk], pos[c0 + j]
+            prop = c - (c - x) * z[:, None]
+            lpn = lnprob(prop)
+            assert not np.any(np.isnan(lpn))
+            r = _draw(seed, step, h, wk, 1)
+            u = _u01(r[0], r[1])
+            with np.errstate(divide="ignore"):
+                acc = np.log(u) < (D - 1.0) * np.log(z) + lpn - lp[wk]
+            pos[wk[acc]], lp[wk[acc]] = prop[acc], lpn[acc]
+            nacc[wk[acc]] += 1
+        chain[it], clp[it] = pos, lp
+    return pos, lp, chain, clp, nacc
+
+
+@pytest.mark.parametrize("W,nsteps", [(48, 40), (1100, 6)])      # fused accept+propose launch (W <= 1024) / separate launches
+def test_device_sampler_equals_an_independent_host_replay(W, nsteps):
+    """N1 pinned independently of the sampler kernels: same Philox draws, proposals and accept/reject restated in
+    NumPy, lnprob of each half-ensemble proposal block from Engine.lnprob -- chain, stored lnprob, acceptance
+    counts and final state must be bit-identical, also across a split run (step0)."""
+    wl = _workload(W=W)
+    eng, p0 = wl.engine, wl.thetas
+    seed = 0x1234_5678_9ABC_DEF1
+    dev = eng.stretch_run(p0, nsteps, seed=seed, a=2.0)
+    ref = _replay_stretch(eng.lnprob, p0, nsteps, 2.0, seed)
+    for d, r in zip(dev, ref):
+        np.testing.assert_array_equal(d, r)
+    assert ref[4].sum() > 0
+    # second leg continuing the stream from step0 with another stretch scale
+    dev2 = eng.stretch_run(dev[0], 3, lnprob=dev[1], seed=seed, a=1.7, step0=nsteps)
+    pos, lp, chain, clp, nacc = _replay_stretch(lambda th: eng.lnprob(th), dev[0], 3, 1.7, seed, step0=nsteps)
+    np.testing.assert_array_equal(dev2[2], chain); np.testing.assert_array_equal(dev2[3], clp)
+    np.testing.assert_array_equal(dev2[4], nacc)
+
+
+def test_initial_nan_lnprob_is_an_error():
+    """emcee and the host sampler raise when the probability function returns NaN; a walker that STARTS at NaN
+    would otherwise stay frozen for the whole run (ln u < NaN is never true)."""
+    wl = _workload()
+    lp = wl.engine.lnprob(wl.thetas)
+    lp[3] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        wl.engine.stretch_run(wl.thetas, 2, lnprob=lp, seed=1)

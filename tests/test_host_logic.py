@@ -1,5 +1,7 @@
 """Host-side mirror of the reference interface (CPU only): table construction, bounds, taps,
 validation, walker sharding, sampler."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,6 +23,7 @@ def _model(spec, fwhm="6.5", **kw):
     cfg = FitConfiguration()
     for z, ion, tr, nc in spec:
         cfg.add_system(z, ion, tr, nc)
+    kw.setdefault("normalize_kernel", False)          # the fixtures hold astropy-4.3.1 (raw) taps
     return VoigtModel(cfg, FWHM=fwhm, **kw)
 
 
@@ -47,7 +50,7 @@ def test_real_cos_tables():
     cfg = FitConfiguration()
     cfg.add_system(0.0, "SiII", [1190.4158, 1193.2897], 1)
     cfg.add_system(0.162005, "HI", [1025.7223], 1)
-    m = VoigtModel(cfg, FWHM=str(z["fwhm"]))
+    m = VoigtModel(cfg, FWHM=str(z["fwhm"]), normalize_kernel=False)
     np.testing.assert_array_equal(m.atomic_lambda0, z["COS__lambda0"])
     np.testing.assert_array_equal(m.N_indices, [0, 0, 1])
     np.testing.assert_array_equal(m.b_indices, [2, 2, 3])
@@ -73,6 +76,64 @@ def test_atomic_lookup_mirrors_rb_setline():
         atomic.lookup(2796.3, "Exact")
     with pytest.raises(ValueError):
         atomic.lookup(2796.3, "nearest")
+
+
+def test_unknown_wavelength_raises_instead_of_snapping_to_an_unrelated_line(tmp_path):
+    """With only the 39 built-in transitions loaded, 'closest' must not turn FeII 1608 into AlII 1670
+    or ZnII 2026 into AlIII 1862 (what an unguarded argmin over a subset does); FitConfiguration and
+    VoigtModel go through the same lookup.  A caller-supplied list in the format of rbvfit's
+    lines/atom_full.dat (rb_setline.py:66-98) lifts the limit, as the reference's full list does."""
+    import importlib
+    from rbvfit_amd.model import FitConfiguration
+    at = importlib.reload(atomic)                       # private table state for this test
+    try:
+        n0 = at.table_size()
+        for lam in (1608.45, 2026.14, 977.02):
+            with pytest.raises(at.UnknownLineError):
+                at.lookup(lam, "closest")
+        with pytest.raises(at.UnknownLineError):
+            FitConfiguration().add_system(0.1, "FeII", [1608.45], 1)
+        assert at.lookup(2796.3, "closest")["name"] == "MgII 2796"       # within 0.5 A: still snaps
+        tab = tmp_path / "atoms.dat"
+        tab.write_text("# ion wrest fval gamma\n"
+                       "FeII   1608.4511 0.057700  2.740E8\n"
+                       "ZnII   2026.1360 0.489000  4.070E8\n"
+                       "\n"
+                       "MgII   2796.3520 0.612300  2.612E8\n")
+        assert at.load_table(str(tab)) == 3
+        assert at.table_size() == n0 + 2                  # the MgII row replaced the built-in one
+        info = at.lookup(1608.45, "closest")
+        assert info["name"] == "FeII 1608" and info["fval"] == np.float32(0.0577) and info["gamma"] == np.float32(2.74e8)
+        assert at.lookup(1500.0, "closest")["name"] in ("SiII 1526", "CIV 1548")   # full list: unconditional, as the reference
+        lst = tmp_path / "sub.lst"
+        lst.write_text("wrest ion n f\n609.95      MgX 609   0.0842       2\n")
+        assert at.load_table(str(lst), fmt="lst", full=False) == 1
+        assert at.lookup(609.9, "Exact" if False else "closest")["fval"] == np.float32(0.0842)
+        with pytest.raises(ValueError):
+            bad = tmp_path / "bad.dat"
+            bad.write_text("FeII 1608.45\n")
+            at.load_table(str(bad))
+    finally:
+        importlib.reload(atomic)
+
+
+REF_ATOMS = "/root/reference/src/rbvfit/lines/atom_full.dat"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_ATOMS), reason="the reference checkout is only present in the build container")
+def test_builtin_rows_equal_the_reference_list_and_the_full_list_loads():
+    import importlib
+    at = importlib.reload(atomic)
+    try:
+        builtin = {(r[0], r[1]): r for r in at._LINES}
+        assert at.load_table(REF_ATOMS) == 320
+        full = {(r[0], r[1]): r for r in at._LINES}
+        assert len(full) == 320                            # every built-in row is a row of the reference's list
+        for key, row in builtin.items():
+            assert np.float32(full[key][2]) == np.float32(row[2]) and np.float32(full[key][3]) == np.float32(row[3])
+        assert at.lookup(1608.45, "closest")["name"] == "FeII 1608"
+    finally:
+        importlib.reload(atomic)
 
 
 def test_set_bounds_matches_fixture():
