@@ -42,7 +42,7 @@ enum {
     VP_EHIP = 2,        /* a HIP runtime call failed */
     VP_ESTATE = 3,      /* call order (e.g. lnprob before bounds/instruments are set) */
     VP_ENOMEM = 4,
-    VP_ENAN = 5      /* a proposal's lnprob was NaN (vp_stretch_run) */
+    VP_ENAN = 5      /* a proposal's lnprob was NaN (vp_stretch_run, vp_slice_run) */
 };
 
 /* LSF dispatch branches of core/voigt_model.py:220-230 */
@@ -136,7 +136,27 @@ int vp_voigt_h(vp_ctx* ctx, int na, const double* a, int nx, const double* x, do
 int vp_stretch_run(vp_ctx* ctx, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
                    uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted);
 
-/* Philox4x32-10 block function used by vp_stretch_run (host evaluation; known-answer tests). */
+/* Device-resident ensemble slice sampler: the walker loop rbvfit delegates to zeus when the fitter is built with
+ * sampler='zeus' (vfit_mcmc.py:425-440 EnsembleSampler construction, :536-540 run_mcmc): `nsteps` iterations of
+ * ensemble slice sampling with the differential move.  Per iteration the ensemble is split at random in two
+ * halves; every walker of the active half slices along mu * 2.38/sqrt(2 D) * (X_l - X_m) (l != m from the other
+ * half) with stepping-out and shrinking.  The ragged sets of still-active walkers are compacted ON the GPU: each
+ * round is one lnprob batch of W/2 rows (active trial points first, the rest prior-rejected filler), and the
+ * host only reads one word per group of rounds to learn whether the half-step is finished.
+ *   pos, lnprob, have_lnprob, seed, step0, chain, chain_lnprob: as in vp_stretch_run.  W even, 4 <= W <= 2048.
+ *   mu         in: initial scale (zeus: 1.0), out: scale after the run.
+ *   tune       != 0: adapt mu after every iteration (mu *= 2 n_expansions / (n_expansions + n_contractions)),
+ *              and stop adapting after `patience` consecutive iterations with |ratio - 1| < tolerance
+ *              (zeus: tolerance 0.05, patience 5); out: whether tuning is still on.
+ *   maxsteps   cap on the stepping-out expansions per slice (zeus: 10000).
+ *   mu_history (nsteps) host or NULL: mu after each iteration.
+ *   n_evals    out (or NULL): lnprob evaluations spent (trial points), ADDED to the value passed in.
+ * Returns VP_ENAN if a trial point's lnprob (or the start state's) is NaN or the start state's is not finite. */
+int vp_slice_run(vp_ctx* ctx, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double* mu,
+                 int* tune, double tolerance, int patience, int maxsteps, uint64_t seed, uint64_t step0,
+                 double* chain, double* chain_lnprob, double* mu_history, int64_t* n_evals);
+
+/* Philox4x32-10 block function used by vp_stretch_run / vp_slice_run (host evaluation; known-answer tests). */
 void vp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 /* Optional per-kernel timing with HIP events recorded on the stream the kernels are launched on

@@ -51,6 +51,8 @@ SIGNATURES = {
     "vp_voigt_h": (C.c_int, [_ctx, C.c_int, _dp, C.c_int, _dp, _dp]),
     "vp_stretch_run": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
                                  _dp, _dp, C.POINTER(C.c_int64)]),
+    "vp_slice_run": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, C.POINTER(C.c_int), C.c_double,
+                               C.c_int, C.c_int, C.c_uint64, C.c_uint64, _dp, _dp, _dp, C.POINTER(C.c_int64)]),
     "vp_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vp_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "vp_profile_read": (C.c_int, [_ctx, _dp, _dp, _dp, C.POINTER(C.c_int)]),

@@ -14,6 +14,7 @@
 #include "../../include/rbvfit_amd.h"
 #include "voigt_kernels.h"
 #include "sampler_kernels.h"
+#include "slice_kernels.h"
 
 namespace {
 
@@ -31,6 +32,9 @@ struct Tuning {
     long zerocopy_max = 1l << 20;    // bytes of theta up to which the host entry reads pinned host memory directly
     int no_zerocopy = 0;
     int no_multipole = 0;       // (read when an instrument is added)
+    int multipole_min = 3;      // smallest cluster (components of one transition) that gets a multipole record
+                                // (2 measured slower on C1: 35.6 vs 32.2 us per 512-walker pass -- the attempt costs an
+                                // un-prefetched record fetch per cluster and pass, and the prep launch grows)
     int span = 0;               // evaluated pixels per tile, 0 = default (read when an instrument is added)
     int waves = 0;              // waves per tile workgroup, 0 = default (read when an instrument is added)
     long lds_pad = 0;           // extra LDS bytes per tile workgroup: occupancy experiments
@@ -43,7 +47,7 @@ const Knob g_knobs[] = {
     VP_KNOB(prep_rpw, "RBVFIT_AMD_PREP_RPW", 0), VP_KNOB(geom, "RBVFIT_AMD_GEOM", 0),
     VP_KNOB(finalize, "RBVFIT_AMD_FINALIZE", 0), VP_KNOB(walker, "RBVFIT_AMD_WALKER", 0),
     VP_KNOB(walker_max_waves, "RBVFIT_AMD_WALKER_MAX_WAVES", 1), VP_KNOB(zerocopy_max, "RBVFIT_AMD_ZEROCOPY_MAX", 1),
-    VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0),
+    VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0),
 };
@@ -215,9 +219,10 @@ int ensure_workspace(vp_ctx* c, int W) {
 
 template <int OUT, bool GENERIC>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
-                 int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag, const vp::InstDev* geom = nullptr) {
+                 int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag, const vp::InstDev* geom = nullptr,
+                 int grid_z = 1) {
     const vp::InstDev& dev = geom ? *geom : in.dev;
-    dim3 grid(W, dev.ntiles);
+    dim3 grid(W, dev.ntiles, grid_z);
     dim3 block(64 * in.nwaves);
     if (dev.method == VP_VOIGT_FAST) {
         if (!GENERIC)
@@ -539,8 +544,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         while (e < L && lambda0[e] == lambda0[l] && zfac[e] == zfac[l]) ++e;
         for (int k = l; k < e; ++k) cl_end[k] = e;
         const bool enable = !c->tune.no_multipole;
-        // (two lines cost about as much as one 13-term expansion: only clusters of >= 3 pay off)
-        if (enable && e - l >= 3 && e - l <= 64 && voigt_method == VP_VOIGT_WOFZ) {
+        if (enable && e - l >= c->tune.multipole_min && e - l <= 64 && voigt_method == VP_VOIGT_WOFZ) {
             cl_mp[l] = (int)cl_first.size();
             cl_first.push_back(l);
             cl_count.push_back(e - l);
@@ -551,10 +555,10 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     int *d_clmp, *d_clend, *d_clfirst, *d_clcount;
     UP(int, cl_mp.data(), L, d_clmp) UP(int, cl_end.data(), L, d_clend)
     UP(int, cl_first.data(), cl_first.size(), d_clfirst) UP(int, cl_count.data(), cl_count.size(), d_clcount)
-    in.lines = vp::LinesDev{L, d_l0, d_fr0, d_g, d_f, d_z, d_n, d_b, d_v, NCm, d_clfirst, d_clcount};
+    in.lines = vp::LinesDev{L, d_l0, d_fr0, d_g, d_f, d_z, d_n, d_b, d_v, NCm, d_clfirst, d_clcount, d_clmp, d_clend};
     vp::InstDev& d = in.dev;
     d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method; d.line_sel = -1;
-    d.NCm = NCm; d.cl_mp = d_clmp; d.cl_end = d_clend;
+    d.NCm = NCm;
 #undef UP
     // Tile geometry: one wave evaluates 2*RB chunks of 64 consecutive pixels (RB register-blocked per pass);
     // a workgroup is 1, 2 or 4 such waves.  Single-wave workgroups need no cross-wave barrier and
@@ -712,25 +716,29 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
     if (W == 0) return VP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
-    Instrument in = c->inst[inst];                 // local copy: line_sel is varied per launch
+    Instrument in = c->inst[inst];                 // local copy: line_sel = -2 makes the line a grid dimension
     in.allocs.clear();
+    in.dev.line_sel = -2;
     const size_t P = in.dev.P, L = in.dev.L;
-    if ((rc = ensure_scratch(c, (size_t)W * P * sizeof(double)))) return rc;
+    // ONE launch per block of walkers evaluates all L per-line profiles (grid = walkers x tiles x lines) straight into
+    // the (w, l, p) layout of `out`; blocks of at most ~1 GiB of output keep the device scratch bounded
+    const size_t per_walker = L * P * sizeof(double);
+    const int wblock = (int)std::max<size_t>(1, std::min<size_t>((size_t)W, ((size_t)1 << 30) / per_walker));
+    if ((rc = ensure_scratch(c, (size_t)wblock * per_walker))) return rc;
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;
     if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
     launch_prep(c, in, c->d_theta, W, 0, nullptr, gen ? c->d_genflag : (int*)nullptr, s);
     const vp::FinalizeArgs nofin{};
-    const int* gf = gen ? c->d_genflag : (const int*)nullptr;
-    for (size_t l = 0; l < L; ++l) {
-        in.dev.line_sel = (int)l;
-        launch_tile<2, false>(in, c->d_lc, nullptr, c->d_scratch, (int)P, 0, W, s, nofin, gf);
-        if (gen) launch_tile<2, true>(in, c->d_lc, nullptr, c->d_scratch, (int)P, 0, W, s, nofin, gf);
+    const size_t nrec = (size_t)(in.dev.L + in.dev.NCm) * vp::LC_STRIDE;
+    for (int w0 = 0; w0 < W; w0 += wblock) {
+        const int nw = std::min(wblock, W - w0);
+        const int* gf = gen ? c->d_genflag + w0 : (const int*)nullptr;
+        launch_tile<2, false>(in, c->d_lc + (size_t)w0 * nrec, nullptr, c->d_scratch, (int)(L * P), 0, nw, s, nofin, gf, nullptr, (int)L);
+        if (gen) launch_tile<2, true>(in, c->d_lc + (size_t)w0 * nrec, nullptr, c->d_scratch, (int)(L * P), 0, nw, s, nofin, gf, nullptr, (int)L);
         HIP_TRY(c, hipGetLastError());
-        // (W, P) rows of line l -> out[w][l][:]
-        HIP_TRY(c, hipMemcpy2DAsync(out + l * P, L * P * sizeof(double), c->d_scratch, P * sizeof(double),
-                                    P * sizeof(double), W, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(out + (size_t)w0 * L * P, c->d_scratch, (size_t)nw * per_walker, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     return VP_OK;
@@ -828,6 +836,128 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     HIP_TRY(c, hipStreamSynchronize(s));
     if (naccepted) for (int w = 0; w < W; ++w) naccepted[w] += (int64_t)h_nacc[w];
     if (h_nan) return fail(c, VP_ENAN, "vp_stretch_run: Probability function returned NaN");
+    return VP_OK;
+}
+
+int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double* mu,
+                 int* tune, double tolerance, int patience, int maxsteps, uint64_t seed, uint64_t step0,
+                 double* chain, double* chain_lnprob, double* mu_history, int64_t* n_evals) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    int rc = check_batch_args(c, W, D, pos, lnprob);
+    if (rc) return rc;
+    if (W < 4 || (W & 1) || W > 2 * vp::SLICE_MAX_HALF)
+        return fail(c, VP_EINVAL, "vp_slice_run: the number of walkers must be even, >= 4 and <= " + std::to_string(2 * vp::SLICE_MAX_HALF));
+    if (nsteps < 0 || !mu || !(*mu > 0.0) || !tune || maxsteps < 1 || patience < 1 || !(tolerance >= 0.0))
+        return fail(c, VP_EINVAL, "vp_slice_run: nsteps >= 0, mu > 0, maxsteps >= 1, patience >= 1, tolerance >= 0 and non-NULL mu/tune required");
+    if ((chain == nullptr) != (chain_lnprob == nullptr)) return fail(c, VP_EINVAL, "vp_slice_run: chain and chain_lnprob go together");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int half = W / 2;
+    if ((rc = ensure_workspace(c, W))) return rc;
+    hipStream_t s = c->stream;
+    // device state (doubles first): pos (W,D) | lp (W) | trial (half,D) | lnp_rows (half) | X0, eta (half,D each) |
+    // Z0, L, R, Wd (half each) | mu[3] | mu_hist (nsteps) | chain chunk; then the integer state
+    const size_t row = (size_t)W * (D + 1);
+    size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
+    const size_t nd = (size_t)W * D + W + (size_t)half * D + half + 2 * (size_t)half * D + 4 * (size_t)half + 4 + (size_t)std::max(nsteps, 1);
+    const size_t ni = (size_t)W + 6 * (size_t)half + 16;                       // perm | J K phase nshr row widx | n_active, nan
+    const size_t bytes = (nd + chunk * row) * sizeof(double) + 4 * sizeof(long long) + ni * sizeof(int) + 64;
+    if ((rc = ensure_scratch(c, bytes))) return rc;
+    double* d_pos = c->d_scratch;
+    double* d_lp = d_pos + (size_t)W * D;
+    double* d_trial = d_lp + W;
+    double* d_rows = d_trial + (size_t)half * D;
+    vp::SliceState st{};
+    st.X0 = d_rows + half;
+    st.eta = st.X0 + (size_t)half * D;
+    st.Z0 = st.eta + (size_t)half * D;
+    st.L = st.Z0 + half; st.R = st.L + half; st.Wd = st.R + half;
+    double* d_mu = st.Wd + half;                                               // 4 doubles (3 used)
+    double* d_muhist = d_mu + 4;
+    double* d_chain = d_muhist + std::max(nsteps, 1);
+    long long* d_ll = reinterpret_cast<long long*>(d_chain + chunk * row);     // n_evals, nexp, ncon, (pad)
+    int* d_int = reinterpret_cast<int*>(d_ll + 4);
+    int* d_perm = d_int;
+    st.J = d_perm + W; st.K = st.J + half; st.phase = st.K + half; st.nshr = st.phase + half; st.row = st.nshr + half;
+    st.widx = st.row + half;
+    int* d_nact = st.widx + half;
+    int* d_nan = d_nact + 1;
+    vp::SliceCounters cn{d_nact, d_ll, d_ll + 1, d_ll + 2, d_nan, d_mu};
+    const double h_mu[4] = {*mu, 0.0, *tune ? 1.0 : 0.0, 0.0};
+    HIP_TRY(c, hipMemcpyAsync(d_pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_mu, h_mu, sizeof(h_mu), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(d_ll, 0, 4 * sizeof(long long), s));
+    HIP_TRY(c, hipMemsetAsync(d_nact, 0, 2 * sizeof(int), s));
+    if (have_lnprob) HIP_TRY(c, hipMemcpyAsync(d_lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, s));
+    else if ((rc = enqueue_lnprob(c, W, d_pos, d_lp, s))) return rc;
+    {   // the start state must be finite everywhere (zeus: "Invalid walker initial positions")
+        std::vector<double> h_lp(W);
+        HIP_TRY(c, hipMemcpyAsync(h_lp.data(), d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (int w = 0; w < W; ++w)
+            if (!(std::fabs(h_lp[w]) <= 1.79e308))
+                return fail(c, VP_ENAN, "vp_slice_run: the initial lnprob of walker " + std::to_string(w) + " is not finite");
+    }
+    const double gamma0 = 2.38 / std::sqrt(2.0 * (double)D);
+    const int thr = ((half + 63) / 64) * 64;
+    int group = 6;                                   // rounds enqueued before the host looks at n_active (adapts to the run)
+    for (int done = 0; done < nsteps;) {
+        const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
+        for (int it = 0; it < n; ++it) {
+            const uint64_t step = step0 + (uint64_t)(done + it);
+            // mu tuning from the PREVIOUS iteration of this call, then this iteration's random split
+            hipLaunchKernelGGL(vp::slice_begin_kernel, dim3(1), dim3(1024), 0, s, W, seed, step, d_perm, cn, (done + it) > 0 ? 1 : 0,
+                               tolerance, patience, (done + it) > 0 ? d_muhist + (done + it - 1) : (double*)nullptr);
+            for (int h = 0; h < 2; ++h) {
+                hipLaunchKernelGGL(vp::slice_init_kernel, dim3(1), dim3(thr), 0, s, d_pos, d_lp, d_perm, half, D, h, seed, step,
+                                   gamma0, maxsteps, st, cn, d_trial);
+                int rounds = 0;
+                for (;;) {
+                    for (int r = 0; r < group; ++r) {
+                        if ((rc = enqueue_lnprob(c, half, d_trial, d_rows, s))) return rc;
+                        hipLaunchKernelGGL(vp::slice_update_kernel, dim3(1), dim3(thr), 0, s, d_pos, d_lp, d_rows, half, D, h, seed,
+                                           step, st, cn, d_trial);
+                    }
+                    rounds += group;
+                    int h_state[2] = {0, 0};
+                    HIP_TRY(c, hipMemcpyAsync(h_state, d_nact, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(c, hipStreamSynchronize(s));
+                    if (h_state[1]) return fail(c, VP_ENAN, "vp_slice_run: Log Probability returned NaN");
+                    if (h_state[0] == 0) break;
+                    if (rounds > 4 * maxsteps + 4096) return fail(c, VP_ESTATE, "vp_slice_run: a slice did not terminate");
+                    group = 2;                       // stragglers: look again after a couple of rounds
+                }
+                group = std::max(3, std::min(16, rounds));   // next half-step: about as many rounds as this one needed
+            }
+            if (chain) {
+                HIP_TRY(c, hipMemcpyAsync(d_chain + (size_t)it * W * D, d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+                HIP_TRY(c, hipMemcpyAsync(d_chain + chunk * (size_t)W * D + (size_t)it * W, d_lp, (size_t)W * sizeof(double),
+                                          hipMemcpyDeviceToDevice, s));
+            }
+        }
+        HIP_TRY(c, hipGetLastError());
+        if (chain) {
+            HIP_TRY(c, hipMemcpyAsync(chain + (size_t)done * W * D, d_chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(chain_lnprob + (size_t)done * W, d_chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
+                                      hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
+        done += n;
+    }
+    // the last iteration's tuning step (so that mu / mu_history cover every iteration of the call)
+    if (nsteps > 0)
+        hipLaunchKernelGGL(vp::slice_tune_kernel, dim3(1), dim3(1), 0, s, cn, tolerance, patience, d_muhist + (nsteps - 1));
+    double h_mu_out[4];
+    long long h_ll[4];
+    HIP_TRY(c, hipMemcpyAsync(pos, d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(lnprob, d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(h_mu_out, d_mu, sizeof(h_mu_out), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(h_ll, d_ll, sizeof(h_ll), hipMemcpyDeviceToHost, s));
+    if (mu_history && nsteps > 0) HIP_TRY(c, hipMemcpyAsync(mu_history, d_muhist, (size_t)nsteps * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *mu = h_mu_out[0];
+    *tune = h_mu_out[2] != 0.0 ? 1 : 0;
+    if (n_evals) *n_evals += (int64_t)h_ll[0];
     return VP_OK;
 }
 

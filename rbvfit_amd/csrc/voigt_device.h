@@ -62,8 +62,11 @@ enum {
     LC_EA2 = 23,   // exp(a^2)
     LC_MODE = 24,  // int[0]: 0: a<=0.1 ; 1: 0.1<a<7 ; 2: a>=7 or a<0 (generic path) ; 3: non-finite -> NaN
                    // int[1]: number of odd Taylor-in-a terms of the core series (mode 0)
-    LC_ACOS = 25,  // erfcx(a) - c*a*sum_n tbl_n                       (mode 1 only)
+    LC_CL = 25,    // int[0]: index of the multipole record if this line is the FIRST member of a cluster, else -1
+                   // int[1]: one past the last line of its cluster   (static per instrument; copied into the record so
+                   //         that it arrives with `mode` in one scalar load, prefetched a line ahead)
     LC_TBL0 = 26,  // 26 entries  0.5*c*a*exp(-h^2 n^2)/(h^2 n^2 + a^2)  (mode 1 only)
+    LC_ACOS = 52,  // erfcx(a) - c*a*sum_n tbl_n                       (mode 1 only)
 };
 
 constexpr double C_FREQ = 2.99792458e18;          // core/voigt_model.py:130

@@ -45,6 +45,8 @@ struct LinesDev {          // static per-instrument line tables (CompiledModelDa
     int NCm;
     const int* cl_first;
     const int* cl_count;
+    const int* cl_mp;      // per line: cluster index if the line is the FIRST of a multipole cluster, else -1
+    const int* cl_end;     // per line: one past the last line of its cluster
 };
 
 struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of a walker)
@@ -66,10 +68,8 @@ struct InstDev {
     int TP;        // output pixels per tile = span - (K-1)
     int ntiles;
     int method;    // VP_VOIGT_*
-    int line_sel;  // -1: all lines; >= 0: only this line (per-line component flux)
+    int line_sel;  // -1: all lines; >= 0: only this line (per-line component flux); -2: line = blockIdx.z (OUT = 2)
     int NCm;       // number of multipole clusters (records follow the line records of a walker)
-    const int* cl_mp;      // per line: cluster index if the line is the FIRST of a multipole cluster, else -1
-    const int* cl_end;     // per line: one past the last line of its cluster
     const double* wave;
     const double* ginv;    // RN(1/wave)
     const double* flux;
@@ -82,10 +82,17 @@ struct InstDev {
 //   WC[m][i] = binom(2m+1, 2i+1) (-1)^i (2(m-i)-1)!! / 2^(m-i)
 // ---------------------------------------------------------------------------------------------
 // Multipole record of a cluster (same 64-double stride as a line record):
-//   [0] A_c  [1] B_c  (y = A_c/wave - B_c)   [2] Yfar (use the expansion when every |y| >= Yfar)
-//   [3..15] Q_2..Q_14 :  tau_cluster(y) = sum_j Q_j y^-j
-constexpr int MP_A = 0, MP_B = 1, MP_YFAR = 2, MP_Q0 = 3, MP_NQ = 13, MP_JMIN = 2;
-constexpr int MP_MWING = 4;      // asymptotic terms kept per member (valid for |x| >= 100)
+//   [0] A_c  [1] B_c  (y = A_c/wave - B_c)
+//   [2..5] Y_0..Y_3: tier k of the expansion may be used where every |y| >= Y_k (inf: never)
+//   [6..20] Q_2..Q_16 :  tau_cluster(y) = sum_j Q_j y^-j
+// Tiers (member |x| floor X_k, ratio floor |y|/max|delta| R_k, terms J_k): the farther the pixels, the
+// fewer terms of the same series are needed (worst relative truncation error over random clusters of
+// 2..8 members against scipy's wofz: 4e-13, 8e-14, 9e-14, 1e-14 -- scripts/multipole_check.py).
+constexpr int MP_A = 0, MP_B = 1, MP_Y0 = 2, MP_NTIER = 4, MP_Q0 = 6, MP_NQ = 15, MP_JMIN = 2;
+constexpr int MP_MWING = 6;      // asymptotic terms kept per member (valid for |x| >= 30)
+constexpr double MP_X[MP_NTIER] = {30.0, 100.0, 500.0, 3000.0};
+constexpr double MP_R[MP_NTIER] = {10.0, 30.0, 100.0, 1000.0};
+constexpr int MP_J0 = 15, MP_J1 = 10, MP_J2 = 7, MP_J3 = 5;
 
 struct WingTable { double c[NWING][NWING]; };
 constexpr WingTable make_wing_table() {
@@ -180,9 +187,10 @@ __device__ __forceinline__ LineScalars line_scalars(const double* __restrict__ t
 //   sum_l sum_{m<4} K_{l,m} x_l^(-2m-2)  =  sum_{j=2..14} Q_j y^-j,
 //   Q_j = sum_l sum_{n=2m+2<=j} K_{l,m} alpha_l^-n (-1)^(j-n) C(j-1, n-1) delta_l^(j-n).
 // A_c is the smallest A_l of the cluster (alpha_l >= 1), B_c centres the delta_l.  The record is used
-// only where every |y| >= Yfar = max(100 + max|delta|, 10 max|delta|): there each member is in its
-// 4-term asymptotic regime (|x_l| >= 100) and the expansion ratio is <= 0.1 (truncation < 2e-12 of
-// an already tiny far-wing tau).  One lane per cluster record; two passes over the members.
+// only where every |y| >= Y_0 = max(30 + max|delta|, 10 max|delta|): there each member is in its
+// 6-term asymptotic regime (|x_l| >= 30) and the expansion ratio is <= 0.1; farther out shorter
+// truncations of the same series serve (tiers above).  One lane per cluster record; two passes over
+// the members.
 __device__ __forceinline__ void prep_cluster(const double* __restrict__ th, const LinesDev& T, int k,
                                              double* __restrict__ rec) {
     const int first = T.cl_first[k], n = T.cl_count[k];
@@ -207,7 +215,7 @@ __device__ __forceinline__ void prep_cluster(const double* __restrict__ th, cons
         const double alpha = s.Ax * fast_rcp(Ac);                // >= 1
         const double delta = Ac * (g0c - g0);                    // x_l = alpha (y + delta)
         dmax = fmax(dmax, fabs(delta));
-        // member's wing coefficients K_m, m < 4, divided by alpha^(2m+2)
+        // member's wing coefficients K_m, m < MP_MWING, divided by alpha^(2m+2)
         double Km[MP_MWING];
         const double a2 = s.a * s.a, pref = s.Tl * (s.a * INV_SQRT_PI);
         const double ia2 = fast_rcp(alpha * alpha);
@@ -220,7 +228,7 @@ __device__ __forceinline__ void prep_cluster(const double* __restrict__ th, cons
             Km[m] = pref * cm * ipow;
             ipow *= ia2;
         }
-        double dpow[MP_NQ + 1];                                  // (-delta)^k, k = 0..13
+        double dpow[MP_NQ + 1];                                  // (-delta)^k, k = 0..MP_NQ
         dpow[0] = 1.0;
 #pragma unroll
         for (int kk = 1; kk <= MP_NQ; ++kk) dpow[kk] = dpow[kk - 1] * (-delta);
@@ -242,7 +250,9 @@ __device__ __forceinline__ void prep_cluster(const double* __restrict__ th, cons
     for (int jq = 0; jq < MP_NQ; ++jq) rec[MP_Q0 + jq] = Q[jq];
     rec[MP_A] = Ac;
     rec[MP_B] = Bc;
-    rec[MP_YFAR] = allok ? fmax(100.0 + dmax, 10.0 * dmax) : __builtin_inf();   // inf: never use the expansion
+#pragma unroll
+    for (int k = 0; k < MP_NTIER; ++k)                          // inf: never use the expansion
+        rec[MP_Y0 + k] = allok ? fmax(MP_X[k] + dmax, MP_R[k] * dmax) : __builtin_inf();
 }
 
 // Record preparation, one LANE per record.  Block roles by blockIdx.x:
@@ -277,6 +287,8 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         rec[LC_CFD] = s.cfd;
         rec[LC_FREQ0] = s.freq0;
         rec[LC_IBF] = s.ibf;
+        reinterpret_cast<int*>(rec + LC_CL)[0] = T.NCm > 0 ? T.cl_mp[l] : -1;
+        reinterpret_cast<int*>(rec + LC_CL)[1] = T.NCm > 0 ? T.cl_end[l] : l + 1;
         return;
     }
     blk -= G.nb_line;
@@ -304,6 +316,8 @@ __global__ __launch_bounds__(64) void prep_h_kernel(const double* __restrict__ a
     double* rec = lc + (size_t)i * LC_STRIDE;
     fill_record(rec, 1.0, a[i]);
     rec[LC_A] = 0; rec[LC_B] = 0; rec[LC_D] = 1; rec[LC_RD] = 1; rec[LC_CFD] = 0; rec[LC_FREQ0] = 0; rec[LC_IBF] = 1;
+    reinterpret_cast<int*>(rec + LC_CL)[0] = -1;
+    reinterpret_cast<int*>(rec + LC_CL)[1] = 0;
 }
 
 
@@ -388,8 +402,8 @@ constexpr int RB = 3;             // 64-pixel chunks per wave pass (register blo
                                   // beats RB=2 and RB=4 by 3-5 %
 
 // s * Horner_M(K, s) for RB independent chunks with the same M; K wave-uniform (SGPR operands).
-template <int M>
-__device__ __forceinline__ void wing_rb(const double (&x)[RB], rec_t K, double (&tau)[RB]) {
+template <int M, class KP>     // KP: rec_t (scalar loads on demand) or a local array already held in SGPRs
+__device__ __forceinline__ void wing_rb(const double (&x)[RB], KP K, double (&tau)[RB]) {
     double s[RB], acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) s[r] = fast_rcp1(x[r] * x[r]);
@@ -406,16 +420,37 @@ __device__ __forceinline__ void wing_rb(const double (&x)[RB], rec_t K, double (
     for (int r = 0; r < RB; ++r) tau[r] = __builtin_fma(acc[r], s[r], tau[r]);
 }
 
+// sum_{j=2}^{J+1} Q_j y^-j for RB independent chunks: the first J terms of a cluster's multipole series.
+template <int J>
+__device__ __forceinline__ void multipole_rb(const double (&y)[RB], rec_t Q, double (&tau)[RB]) {
+    double q[RB], acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) q[r] = fast_rcp1(y[r]);
+    const double qt = Q[J - 1];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = qt;
+#pragma unroll
+    for (int jq = J - 2; jq >= 0; --jq) {
+        const double qj = Q[jq];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_fma(acc[r], q[r], qj);
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) tau[r] = __builtin_fma(acc[r], q[r] * q[r], tau[r]);
+}
+
 // The eager block of a record: A, B, K0..K5 (one 64-byte scalar load) + mode.
-struct Eager {            // prefetched one line ahead: what the tier decision needs
-    double A, B;
-    int mode;
+struct Eager {            // prefetched one line ahead: what the tier decision needs.  (Fetching K0..K5 along with it, so
+    double A, B;          // that the far tiers issue no load behind their decision, measured 0.5-2 % SLOWER on C1-C4:
+    int mode, mp, cl_end; // the exposed scalar-load latency is covered by the other waves, the 20 extra SGPR spills are not.)
 };
 __device__ __forceinline__ Eager load_eager(rec_t rec) {
     Eager e;
     e.A = rec[LC_A];
     e.B = rec[LC_B];
     e.mode = rec_int(rec, LC_MODE, 0);
+    e.mp = rec_int(rec, LC_CL, 0);
+    e.cl_end = rec_int(rec, LC_CL, 1);
     return e;
 }
 
@@ -471,7 +506,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     const int nout = p1 - p0;
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
-    const int lane = tid & 63, wid = SOLO ? 0 : (tid >> 6);
+    const int lane = SOLO ? tid : (tid & 63), wid = SOLO ? 0 : (tid >> 6);     // SOLO: tid IS the lane
     const int TILE_THREADS = SOLO ? 64 : nthreads, nwaves = SOLO ? 1 : (nthreads >> 6);
     double* __restrict__ daw = fl + I.span + FL_PAD + 4;   // Dawson table for the line cores (16-B aligned)
     double* __restrict__ ktap = daw + DAW_LDS_DOUBLES; // LSF taps, read back as LDS broadcasts
@@ -519,29 +554,33 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                 for (int l = l0; l < l1; ++l) {
                     // far from a whole cluster of components?  one multipole evaluation replaces all of
                     // its member lines (only tried at the first line of a cluster that fits this block)
-                    const int mp = (I.NCm > 0 && I.line_sel < 0) ? I.cl_mp[l] : -1;
-                    if (mp >= 0 && I.cl_end[l] <= l1) {
+                    const int mp = (I.line_sel < 0) ? nxt.mp : -1;
+                    if (mp >= 0 && nxt.cl_end <= l1) {
                         rec_t mrec = lcw + (size_t)(I.L + mp) * LC_STRIDE;
-                        const double Ac = mrec[MP_A], Bc = mrec[MP_B], yfar = mrec[MP_YFAR];
+                        // A, B and the four tier radii arrive with ONE scalar load (no load behind a tier decision
+                        // except the Q_j themselves)
+                        const double Ac = mrec[MP_A], Bc = mrec[MP_B];
+                        const double y0 = mrec[MP_Y0], y1 = mrec[MP_Y0 + 1], y2 = mrec[MP_Y0 + 2], y3 = mrec[MP_Y0 + 3];
                         double y[RB];
 #pragma unroll
                         for (int r = 0; r < RB; ++r) y[r] = __builtin_fma(Ac, g[r], -Bc);
                         double ym = fabs(y[0]);
 #pragma unroll
                         for (int r = 1; r < RB; ++r) ym = fmin(ym, fabs(y[r]));
-                        if (__ballot(!(ym >= yfar)) == 0ull) {      // every lane far enough (NaN counts as near)
-                            double q[RB], acc[RB];
-#pragma unroll
-                            for (int r = 0; r < RB; ++r) { q[r] = fast_rcp1(y[r]); acc[r] = mrec[MP_Q0 + MP_NQ - 1]; }
-#pragma unroll
-                            for (int jq = MP_NQ - 2; jq >= 0; --jq) {
-                                const double qj = mrec[MP_Q0 + jq];
-#pragma unroll
-                                for (int r = 0; r < RB; ++r) acc[r] = __builtin_fma(acc[r], q[r], qj);
+                        const bool far0 = __ballot(!(ym >= y0)) == 0ull;      // every lane far enough (NaN counts as near)
+                        const bool far1 = VP_NONE_BELOW(ym, y1), far2 = VP_NONE_BELOW(ym, y2), far3 = VP_NONE_BELOW(ym, y3);
+                        if (far0) {
+                            if (far1) {
+                                if (far2) {
+                                    if (far3) multipole_rb<MP_J3>(y, mrec + MP_Q0, tau);
+                                    else multipole_rb<MP_J2>(y, mrec + MP_Q0, tau);
+                                } else {
+                                    multipole_rb<MP_J1>(y, mrec + MP_Q0, tau);
+                                }
+                            } else {
+                                multipole_rb<MP_J0>(y, mrec + MP_Q0, tau);
                             }
-#pragma unroll
-                            for (int r = 0; r < RB; ++r) tau[r] = __builtin_fma(acc[r], q[r] * q[r], tau[r]);
-                            l = I.cl_end[l] - 1;                       // skip the member lines
+                            l = nxt.cl_end - 1;                        // skip the member lines
                             nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
                             continue;
                         }
@@ -793,6 +832,12 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
     if (GENERIC ? (gen == 0) : (gen != 0)) return;   // the other launch owns this walker
     rec_t lcw = as_rec(lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE);
+    if (OUT == 2 && I.line_sel == -2) {          // per-line profiles of ALL lines in one launch: grid.z = line, out (W, L, P)
+        InstDev J = I;
+        J.line_sel = blockIdx.z;
+        tile_work<METHOD, OUT, GENERIC, false>(J, lcw, fl, t, w, threadIdx.x, blockDim.x, pre, out + (size_t)blockIdx.z * I.P, out_stride);
+        return;
+    }
     const double wsum = tile_work<METHOD, OUT, GENERIC, false>(I, lcw, fl, t, w, threadIdx.x, blockDim.x, pre, out, out_stride);
     if (OUT == 0) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -876,6 +921,8 @@ __device__ __forceinline__ void prep_record_lanes(const double* __restrict__ th,
         rec[LC_T] = Tl;
         rec[LC_Y] = a;
         rec[LC_ACOS] = 0.0;                   // (the Alg. 916 table of mode 1 is only read by the GENERIC tile kernel)
+        reinterpret_cast<int*>(rec + LC_CL)[0] = T.NCm > 0 ? T.cl_mp[l] : -1;
+        reinterpret_cast<int*>(rec + LC_CL)[1] = T.NCm > 0 ? T.cl_end[l] : l + 1;
         reinterpret_cast<int*>(rec + LC_MODE)[0] = mode;
         reinterpret_cast<int*>(rec + LC_MODE)[1] = core_terms(a);
         // exp(a^2) by its Taylor terms as in fill_record (mode 0: a <= 0.1); other modes never read it here

@@ -179,13 +179,42 @@ class VoigtModel:
             print(f"Compiling VoigtModel: {3 * self.total_components} parameters, {self.n_lines} lines")
         return CompiledVoigtModel(data, device_id)
 
-    def evaluate(self, theta, wavelength, return_unconvolved: bool = False):
+    def evaluate(self, theta, wavelength, return_components: bool = False, return_unconvolved: bool = False):
         """Analysis-time evaluation (core/voigt_model.py:509-558).  Note T10: the reference's
-        ``evaluate`` always uses the exact Voigt function, whatever ``voigt_method`` says."""
+        ``evaluate`` always uses the exact Voigt function, whatever ``voigt_method`` says.
+        ``return_components=True`` returns the reference's dictionary (voigt_model.py:232-259):
+        ``flux`` (convolved unless ``return_unconvolved``), ``components`` (list of the L unconvolved
+        per-line profiles exp(-tau_l)) and ``component_info`` (one dict per line: line_index, lambda0,
+        gamma, f_value, z_total, N_value, b_value, v_value)."""
         data = CompiledModelData(self.atomic_lambda0, self.atomic_gamma, self.atomic_f, self.z_factors,
                                  self.N_indices, self.b_indices, self.v_indices, self.taps, self.lsf_mode,
                                  self.n_lines, self.total_components, "wofz")
-        return CompiledVoigtModel(data).model_flux(theta, wavelength, convolved=not return_unconvolved)
+        cm = CompiledVoigtModel(data)
+        try:
+            flux = cm.model_flux(theta, wavelength, convolved=not return_unconvolved)
+            if not return_components:
+                return flux
+            theta = np.asarray(theta, dtype=np.float64)
+            if theta.ndim != 1:
+                raise ValueError("return_components=True takes a single theta, as the reference does")
+            comps = cm.components(theta, wavelength)
+            return {"flux": flux, "components": [comps[i] for i in range(self.n_lines)],
+                    "component_info": component_info(data, theta)}
+        finally:
+            cm.close()
+
+
+def component_info(data: "CompiledModelData", theta) -> list:
+    """The per-line bookkeeping of ``_evaluate_compiled_model(..., return_components=True)``
+    (voigt_model.py:240-253), formed with the reference's operations (:192-200)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    N_linear = 10 ** theta[np.asarray(data.N_indices)]
+    b_values = theta[np.asarray(data.b_indices)]
+    v_values = theta[np.asarray(data.v_indices)]
+    z_total = np.asarray(data.z_factors) * (1 + v_values / 299792.458) - 1
+    return [{"line_index": i, "lambda0": float(data.atomic_lambda0[i]), "gamma": float(data.atomic_gamma[i]),
+             "f_value": float(data.atomic_f[i]), "z_total": float(z_total[i]), "N_value": float(N_linear[i]),
+             "b_value": float(b_values[i]), "v_value": float(v_values[i])} for i in range(int(data.n_lines))]
 
 
 class CompiledVoigtModel:
@@ -212,6 +241,11 @@ class CompiledVoigtModel:
                 self._engines.pop(next(iter(self._engines))).close()
             self._engines[key] = eng
         return eng
+
+    def close(self):
+        for eng in self._engines.values():
+            eng.close()
+        self._engines = {}
 
     def model_flux(self, theta, wavelength, convolved: bool = True) -> np.ndarray:
         theta = np.asarray(theta, dtype=np.float64)

@@ -240,6 +240,50 @@ class EnsembleSliceSampler:
         return c.reshape(-1, self.ndim) if flat else c
 
 
+class DeviceSliceSampler:
+    """Ensemble slice sampling with the whole walker loop on the GPU (``vp_slice_run``,
+    csrc/slice_kernels.h): the same move as ``EnsembleSliceSampler`` / zeus, but every stepping-out or
+    shrinking round is a lnprob batch enqueued from the host without looking at its result -- the
+    active walkers are compacted in HBM, and the host reads one word per group of rounds.  Draws are
+    Philox4x32-10 keyed by (seed, step, half, walker, purpose); successive ``run_mcmc`` calls continue
+    the stream and the tuned ``mu``.  ``engine`` is the ``rbvfit_amd.Engine`` (``vfit.engine``)."""
+
+    def __init__(self, nwalkers: int, ndim: int, engine, mu: float = 1.0, maxsteps: int = 10000, tune: bool = True,
+                 tolerance: float = 0.05, patience: int = 5, seed: Optional[int] = None):
+        if nwalkers % 2 or nwalkers < 2 * ndim:
+            raise ValueError("nwalkers must be even and at least 2*ndim (as zeus requires)")
+        self.nwalkers, self.ndim, self.engine = nwalkers, ndim, engine
+        self.mu, self.maxsteps, self.tune = float(mu), int(maxsteps), bool(tune)
+        self.tolerance, self.patience = float(tolerance), int(patience)
+        self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+        self.chain = None
+        self.lnprobability = None
+        self.nsteps = 0
+        self.n_lnprob_evals = 0
+        self.mu_history = []
+
+    def run_mcmc(self, p0, nsteps: int, lnprob0=None, store: bool = True):
+        pos = np.array(p0, dtype=np.float64)
+        if pos.shape != (self.nwalkers, self.ndim):
+            raise ValueError(f"initial state must have shape ({self.nwalkers}, {self.ndim})")
+        r = self.engine.slice_run(pos, nsteps, lnprob=lnprob0, mu=self.mu, tune=self.tune, tolerance=self.tolerance,
+                                  patience=self.patience, maxsteps=self.maxsteps, seed=self.seed, step0=self.nsteps,
+                                  store_chain=store)
+        self.mu, self.tune = r["mu"], r["tune"]
+        self.mu_history.extend(r["mu_history"].tolist())
+        self.n_lnprob_evals += r["n_evals"]
+        if store:
+            self.chain = r["chain"] if self.chain is None else np.concatenate([self.chain, r["chain"]])
+            self.lnprobability = (r["chain_lnprob"] if self.lnprobability is None
+                                  else np.concatenate([self.lnprobability, r["chain_lnprob"]]))
+        self.nsteps += nsteps
+        return r["pos"], r["lnprob"]
+
+    def get_chain(self, discard: int = 0, flat: bool = False):
+        c = self.chain[discard:]
+        return c.reshape(-1, self.ndim) if flat else c
+
+
 def gelman_rubin(chain) -> np.ndarray:
     """Potential scale reduction R-hat per parameter for a (nsteps, nwalkers, D) chain, walkers as the
     parallel chains -- the diagnostic the reference prints for zeus runs (vfit_mcmc.py:633-640)."""

@@ -240,8 +240,9 @@ class vfit:
         call per half-ensemble.  ``sampler``: 'emcee' (``vectorize=True``), 'host'
         (``rbvfit_amd.sampler.StretchMoveSampler``), 'device' (``DeviceStretchSampler``: the whole
         loop in HBM), 'zeus' / 'host-slice' (ensemble slice sampling: zeus itself or
-        ``EnsembleSliceSampler``, ragged batches) or 'auto' (the constructor's ``sampler=`` choice:
-        emcee/zeus when installed, else the matching host driver).  ``use_pool`` must stay False: a HIP
+        ``EnsembleSliceSampler``, ragged batches), 'device-slice' (``DeviceSliceSampler``: slice sampling
+        with the ragged active sets compacted on the GPU) or 'auto' (the constructor's ``sampler=``
+        choice: emcee/zeus when installed, else the matching host driver).  ``use_pool`` must stay False: a HIP
         context cannot be shared with forked workers, and batching replaces the Pool."""
         if use_pool:
             raise ValueError("use_pool=True is not supported: the batched GPU lnprob replaces the fork Pool")
@@ -251,8 +252,8 @@ class vfit:
         rng = np.random.default_rng(seed)
         guesses = initialize_walkers(self.theta, self.lb, self.ub, self.no_of_Chain, self.perturbation,
                                      self.lnprob, rng)
-        if sampler not in ("auto", "emcee", "zeus", "host", "host-slice", "device"):
-            raise ValueError("sampler must be 'auto', 'emcee', 'zeus', 'host', 'host-slice' or 'device'")
+        if sampler not in ("auto", "emcee", "zeus", "host", "host-slice", "device", "device-slice"):
+            raise ValueError("sampler must be 'auto', 'emcee', 'zeus', 'host', 'host-slice', 'device' or 'device-slice'")
         if sampler == "auto":                          # the constructor's sampler= choice, as in the reference
             try:
                 if self.sampler_name == "zeus":
@@ -275,6 +276,10 @@ class vfit:
             import emcee
             sampler = emcee.EnsembleSampler(self.no_of_Chain, self.ndim, self.lnprob, vectorize=True)
             sampler.run_mcmc(guesses, self.no_of_steps, progress=verbose)
+        elif sampler == "device-slice":                # zeus' move with the whole walker loop on the GPU (vp_slice_run)
+            from .sampler import DeviceSliceSampler
+            sampler = DeviceSliceSampler(self.no_of_Chain, self.ndim, self.engine, seed=seed)
+            sampler.run_mcmc(guesses, self.no_of_steps)
         elif sampler == "device":                      # whole walker loop on the GPU (vp_stretch_run)
             from .sampler import DeviceStretchSampler
             sampler = DeviceStretchSampler(self.no_of_Chain, self.ndim, self.engine, seed=seed)

@@ -243,6 +243,20 @@ def test_components_and_batched_gradient():
         tau = vo.voigt_tau(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, N, b, wr)
         np.testing.assert_allclose(comp[i], np.exp(-tau), rtol=0, atol=FLUX_ATOL)
         np.testing.assert_allclose(np.prod(comp[i], axis=0), cm.model_flux(t, z["G__wave"], convolved=False), rtol=0, atol=1e-12)
+    # VoigtModel.evaluate(return_components=True): the reference's dictionary (voigt_model.py:232-259, 509-558)
+    ev = model.evaluate(th[0], z["G__wave"], return_components=True)
+    assert set(ev) == {"flux", "components", "component_info"} and len(ev["components"]) == 4
+    np.testing.assert_array_equal(ev["flux"], cm.model_flux(th[0], z["G__wave"]))
+    np.testing.assert_array_equal(np.array(ev["components"]), comp[0])
+    t = th[0]
+    for i, info in enumerate(ev["component_info"]):
+        assert info["line_index"] == i and info["lambda0"] == float(data.atomic_lambda0[i])
+        assert info["gamma"] == float(data.atomic_gamma[i]) and info["f_value"] == float(data.atomic_f[i])
+        assert info["N_value"] == float(10 ** t[data.N_indices[i]]) and info["b_value"] == t[data.b_indices[i]]
+        assert info["v_value"] == t[data.v_indices[i]]
+        assert info["z_total"] == float(data.z_factors[i] * (1 + t[data.v_indices[i]] / 299792.458) - 1)
+    np.testing.assert_array_equal(model.evaluate(th[0], z["G__wave"], return_unconvolved=True),
+                                  cm.model_flux(th[0], z["G__wave"], convolved=False))
     inst = {"G": {"model": model, "wave": z["G__wave"], "flux": z["G__flux"], "error": z["G__error"]}}
     fit = vfit(inst, z["theta_true"], z["lb"], z["ub"])
     try:

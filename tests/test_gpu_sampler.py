@@ -249,3 +249,134 @@ def test_initial_nan_lnprob_is_an_error():
     lp[3] = np.nan
     with pytest.raises(ValueError, match="NaN"):
         wl.engine.stretch_run(wl.thetas, 2, lnprob=lp, seed=1)
+
+
+# ---- independent host replay of vp_slice_run (csrc/slice_kernels.h) ----------------------------------------
+def _replay_slice(lnprob, p0, nsteps, seed, mu=1.0, tune=True, tolerance=0.05, patience=5, maxsteps=10000, step0=0):
+    """zeus' ensemble slice sampling (the reference's sampler='zeus', vfit_mcmc.py:425-440) as vp_slice_run performs
+    it, restated in NumPy with the same Philox draws: random split by ranking 64-bit keys, differential move,
+    per-walker state machine OUT_L -> OUT_R -> SHRINK -> DONE, one lnprob batch per round over the walkers that are
+    not DONE (active trial points first, then +inf filler rows to the fixed batch size W/2)."""
+    pos = np.array(p0, dtype=np.float64)
+    W, D = pos.shape
+    half = W // 2
+    lp = lnprob(pos)
+    gamma0 = 2.38 / np.sqrt(2.0 * D)
+    good, n_evals = 0, 0
+    chain, clp, hist = np.empty((nsteps, W, D)), np.empty((nsteps, W)), np.empty(nsteps)
+    allw = np.arange(W)
+    for it in range(nsteps):
+        step = step0 + it
+        r = _draw(seed, step, 0, allw, 16)
+        keys = (r[0] << np.uint64(32)) | r[1]
+        perm = np.lexsort((allw, keys))                       # rank by key, ties by index
+        nexp = ncon = 0
+        for h in (0, 1):
+            S, Cc = perm[h * half:(h + 1) * half], perm[(1 - h) * half:(2 - h) * half]
+            ra, rb, rc = _draw(seed, step, h, S, 17), _draw(seed, step, h, S, 18), _draw(seed, step, h, S, 19)
+            l = np.minimum((_u01(ra[0], ra[1]) * float(half)).astype(np.int64), half - 1)
+            mo = np.minimum((_u01(ra[2], ra[3]) * float(half - 1)).astype(np.int64), half - 2)
+            m = (l + 1 + mo) % half
+            X0 = pos[S].copy()
+            eta = (mu * gamma0) * (pos[Cc[l]] - pos[Cc[m]])
+            Z0 = lp[S] + np.log(_u01(rb[0], rb[1]))
+            L = -_u01(rb[2], rb[3]); R = L + 1.0
+            J = np.minimum((float(maxsteps) * _u01(rc[0], rc[1])).astype(np.int64), maxsteps - 1)
+            K = (maxsteps - 1) - J
+            phase = np.zeros(half, dtype=int); nshr = np.zeros(half, dtype=np.int64); Wd = np.zeros(half)
+            while True:
+                phase[(phase == 0) & (J <= 0)] = 1
+                phase[(phase == 1) & (K <= 0)] = 2
+                act = np.flatnonzero(phase != 3)
+                if act.size == 0:
+                    break
+                t = np.where(phase[act] == 0, L[act], R[act])
+                sh = act[phase[act] == 2]
+                for k in sh:                                   # the c-th shrink draw of walker S[k]: purpose 32 + c
+                    rr = _draw(seed, step, h, S[k:k + 1], 32 + int(nshr[k]))
+                    Wd[k] = L[k] + _u01(rr[0], rr[1])[0] * (R[k] - L[k])
+                t = np.where(phase[act] == 2, Wd[act], t)
+                batch = np.full((half, D), np.inf)
+                batch[:act.size] = X0[act] + t[:, None] * eta[act]
+                v = lnprob(batch)[:act.size]
+                n_evals += act.size
+                assert not np.any(np.isnan(v))
+                up = v > Z0[act]
+                for k, ok, val, tk in zip(act, up, v, t):
+                    if phase[k] == 0:
+                        if ok: L[k] -= 1.0; J[k] -= 1; nexp += 1
+                        else: phase[k] = 1
+                    elif phase[k] == 1:
+                        if ok: R[k] += 1.0; K[k] -= 1; nexp += 1
+                        else: phase[k] = 2
+                    else:
+                        if ok:
+                            pos[S[k]] = X0[k] + tk * eta[k]; lp[S[k]] = val; phase[k] = 3
+                        else:
+                            if tk < 0: L[k] = tk
+                            else: R[k] = tk
+                            nshr[k] += 1; ncon += 1
+        if tune:
+            ratio = 2.0 * max(1, nexp) / (max(1, nexp) + ncon)
+            mu *= ratio
+            good = good + 1 if abs(ratio - 1.0) < tolerance else 0
+            if good >= patience:
+                tune = False
+        hist[it] = mu
+        chain[it], clp[it] = pos, lp
+    return dict(pos=pos, lnprob=lp, chain=chain, chain_lnprob=clp, mu=mu, tune=tune, mu_history=hist, n_evals=n_evals)
+
+
+@pytest.mark.parametrize("W,nsteps", [(16, 12), (48, 25)])
+def test_device_slice_sampler_equals_an_independent_host_replay(W, nsteps):
+    """N1, second move: vp_slice_run against a NumPy restatement that shares only Engine.lnprob and the Philox
+    function -- chain, stored lnprob, mu trajectory and the number of lnprob evaluations must be identical, also
+    across a split run."""
+    wl = _workload(W=W)
+    eng, p0 = wl.engine, wl.thetas
+    seed = 0xC0FFEE_1234_5678
+    dev = eng.slice_run(p0, nsteps, seed=seed)
+    ref = _replay_slice(eng.lnprob, p0, nsteps, seed)
+    for k in ("chain", "chain_lnprob", "pos", "lnprob", "mu_history"):
+        np.testing.assert_array_equal(dev[k], ref[k], err_msg=k)
+    assert dev["n_evals"] == ref["n_evals"] and dev["mu"] == ref["mu"] and dev["tune"] == ref["tune"]
+    assert np.all(dev["chain"] >= wl.lb) and np.all(dev["chain"] <= wl.ub)
+    np.testing.assert_array_equal(eng.lnprob(dev["chain"][-1]), dev["chain_lnprob"][-1])
+    # every walker moves every iteration (slice sampling has no rejections)
+    full = np.concatenate([p0[None], dev["chain"]])
+    assert np.all(np.any(full[1:] != full[:-1], axis=2))
+    # continuation: run(n1) then run(n2, step0=n1, mu, tune) == run(n1+n2)
+    a = eng.slice_run(p0, 5, seed=seed)
+    b = eng.slice_run(a["pos"], nsteps - 5, lnprob=a["lnprob"], seed=seed, step0=5, mu=a["mu"], tune=a["tune"])
+    np.testing.assert_array_equal(np.concatenate([a["chain"], b["chain"]])[:5], dev["chain"][:5])
+    np.testing.assert_array_equal(b["chain"][0], dev["chain"][5])      # (the patience counter restarts: compare the first step)
+
+
+def test_device_slice_sampler_distribution_and_vfit_switch():
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    from rbvfit_amd.sampler import DeviceSliceSampler
+    from rbvfit_amd.vfit import vfit
+    wl = _workload()
+    eng, p0 = wl.engine, wl.thetas
+    sl = DeviceSliceSampler(48, 6, eng, seed=3)
+    sl.run_mcmc(p0, 200)
+    sl.run_mcmc(sl.chain[-1], 400, lnprob0=sl.lnprobability[-1])
+    assert sl.chain.shape == (600, 48, 6) and len(sl.mu_history) == 600 and sl.n_lnprob_evals > 600 * 48 * 3
+    dev = eng.stretch_run(p0, 4000, seed=1)[2][1000:].reshape(-1, 6)
+    s = sl.get_chain(discard=200, flat=True)
+    sd = dev.std(axis=0)
+    assert np.all(np.abs(s.mean(axis=0) - dev.mean(axis=0)) < 0.5 * sd)
+    assert np.all(s.std(axis=0) / sd > 0.6) and np.all(s.std(axis=0) / sd < 1.6)
+    wave, flux, err = wl.spectra[0]
+    cfg = FitConfiguration(); cfg.add_system(0.348, "MgII", [2796.35, 2803.53], 2)
+    fit = vfit({"G": {"model": VoigtModel(cfg, FWHM="6.5"), "wave": wave, "flux": flux, "error": err}},
+               wl.theta_true, wl.lb, wl.ub, no_of_Chain=24, no_of_steps=30, sampler="zeus")
+    try:
+        smp = fit.runmcmc(seed=2, sampler="device-slice")
+        assert type(smp).__name__ == "DeviceSliceSampler" and smp.chain.shape == (30, 24, 6)
+        np.testing.assert_array_equal(smp.lnprobability[-1], fit.lnprob(smp.chain[-1]))
+    finally:
+        fit.close()
+    lp = eng.lnprob(p0); lp[2] = -np.inf
+    with pytest.raises(ValueError):
+        eng.slice_run(p0, 2, lnprob=lp, seed=1)
