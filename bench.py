@@ -339,6 +339,20 @@ def rank_main(args):
         pr = eng.profile_read()
         eng.profile_enable(False)
         tile_ms = pr["tile_ms"] / max(pr["n_tile_launches"], 1)
+        kind = eng.last_launch_kind
+        kernel_name = "vp::walker_kernel<0, false>" if kind == "walker" else "vp::tile_kernel<0, 0, false>"
+        timing_note = "HIP events around every launch of the kernel on its stream"
+        if kind == "walker":
+            # the step IS one kernel: a pair of events around EVERY launch would put ~4 us of record gaps on a 30 us
+            # kernel, so the events bracket nprof back-to-back launches instead (mean duration incl. dispatch gaps)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(nprof):
+                eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            tile_ms = e0.elapsed_time(e1) / nprof
+            timing_note = f"HIP events around {nprof} back-to-back launches of the kernel on its stream (one launch per step)"
         bytes_per_launch = wl.algorithmic_bytes_per_eval * W / len(wl.pixels)
         achieved = bytes_per_launch / (tile_ms * 1e-3) / 1e9
         # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 per the gfx950 guide
@@ -354,7 +368,7 @@ def rank_main(args):
         except Exception:
             pass
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, traffic_source=traffic_src, kernel=pr.get("kernel", "vp::tile_kernel"), avg_kernel_ms=tile_ms,
+                    traffic=traffic, traffic_source=traffic_src, kernel=kernel_name, avg_kernel_ms=tile_ms, kernel_timing=timing_note,
                     algorithmic_bytes_per_launch=bytes_per_launch, launches_per_step=pr["n_tile_launches"] / nprof,
                     prep_ms=pr["prep_ms"] / nprof, finalize_ms=pr.get("finalize_ms", 0.0) / nprof,
                     note="kernel is fp64-VALU / latency bound; spectra are shared by all walkers through L2/MALL, "

@@ -176,6 +176,28 @@ int vp_profile_read(vp_ctx* ctx, double* prep_ms, double* tile_ms, double* final
  * afterwards.  Unknown name -> VP_EINVAL. */
 int vp_set_option(vp_ctx* ctx, const char* name, long value);
 
+/* ---- several GPUs from one process (the torch-free, RCCL-free form of the walker sharding) ----
+ * A vp_multi owns one vp_ctx per listed device (a device may be listed more than once) with identical static
+ * data.  vp_multi_lnprob_batch cuts the (W, D) batch into contiguous blocks of ceil(W / n_devices) rows -- the
+ * partition of rbvfit_amd.dist.shard_bounds; trailing devices get fewer rows or none (ragged zeus batches with
+ * W < n_devices) --, enqueues every block on its device before waiting for any, and each block's lnprob is
+ * copied straight into its slice of `out`: no collective, the gather is the D2H copies.  Replaces the reference's
+ * fork Pool fan-out (vfit_mcmc.py:35-49, 408-440) for callers that bind the C ABI without torch.  The per-device
+ * contexts are reachable through vp_multi_ctx (e.g. for vp_set_option); errors name the failing device slot. */
+typedef struct vp_multi vp_multi;
+int vp_multi_create(vp_multi** out, int n_devices, const int* device_ids);
+int vp_multi_destroy(vp_multi* m);
+int vp_multi_n_devices(const vp_multi* m);
+vp_ctx* vp_multi_ctx(vp_multi* m, int i);
+int vp_multi_set_bounds(vp_multi* m, int D, const double* lb, const double* ub);
+int vp_multi_add_instrument(vp_multi* m, int P, const double* wave, const double* flux, const double* inv_sigma2,
+                            const double* log_inv_sigma2, int L, const double* lambda0, const double* gamma,
+                            const double* f, const double* zfac, const int32_t* N_idx, const int32_t* b_idx,
+                            const int32_t* v_idx, int K, const double* taps, int lsf_mode, int voigt_method,
+                            int* inst_index);
+int vp_multi_lnprob_batch(vp_multi* m, int W, int D, const double* theta, double* out);
+const char* vp_multi_last_error(const vp_multi* m);
+
 /* The context's own stream (a hipStream_t, created non-blocking): what hip_stream == NULL selects in the
  * *_device entry points.  Lets a host framework order its own work against it (e.g.
  * torch.cuda.ExternalStream(handle).wait_stream(...)). */
@@ -186,6 +208,9 @@ int vp_num_instruments(const vp_ctx* ctx);
 int vp_ndim(const vp_ctx* ctx);
 int vp_instrument_pixels(const vp_ctx* ctx, int inst);
 int vp_device_id(const vp_ctx* ctx);
+/* Launch structure the last lnprob batch used: 0 = prep_lines_kernel + tile_kernel (+ finalize_kernel),
+ * 1 = walker_kernel (the whole batch in one launch). */
+int vp_last_launch_kind(const vp_ctx* ctx);
 
 /* Text of the last error on this context (or of the last failed vp_ctx_create when ctx is NULL).
  * Valid until the next call on the same context/thread. */

@@ -53,6 +53,15 @@ SIGNATURES = {
                                  _dp, _dp, C.POINTER(C.c_int64)]),
     "vp_slice_run": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, C.POINTER(C.c_int), C.c_double,
                                C.c_int, C.c_int, C.c_uint64, C.c_uint64, _dp, _dp, _dp, C.POINTER(C.c_int64)]),
+    "vp_multi_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_int)]),
+    "vp_multi_destroy": (C.c_int, [_ctx]),
+    "vp_multi_n_devices": (C.c_int, [_ctx]),
+    "vp_multi_ctx": (_ctx, [_ctx, C.c_int]),
+    "vp_multi_set_bounds": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
+    "vp_multi_add_instrument": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp,
+                                          _ip, _ip, _ip, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "vp_multi_lnprob_batch": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp]),
+    "vp_multi_last_error": (C.c_char_p, [_ctx]),
     "vp_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vp_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "vp_profile_read": (C.c_int, [_ctx, _dp, _dp, _dp, C.POINTER(C.c_int)]),
@@ -61,6 +70,7 @@ SIGNATURES = {
     "vp_ndim": (C.c_int, [_ctx]),
     "vp_instrument_pixels": (C.c_int, [_ctx, C.c_int]),
     "vp_device_id": (C.c_int, [_ctx]),
+    "vp_last_launch_kind": (C.c_int, [_ctx]),
     "vp_last_error": (C.c_char_p, [_ctx]),
 }
 

@@ -26,9 +26,7 @@ struct Tuning {
     int prep_rpw = 64;          // records per wave of prep_lines_kernel
     int geom = -1;              // tile geometry: -1 by batch size, 0 two-pass tiles, 1 one-pass tiles
     int finalize = -1;          // final reduction: -1 by batch size, 0 own launch, 1 ticket in the tile kernel
-    int walker = 0;             // walker_kernel (one launch per batch): -1 by batch size, 0 never, 1 whenever possible
-                                // (measured slower than the three launches at every batch size so far: off by default)
-    long walker_max_waves = 3072;    // ... by batch size: used while W x tiles <= this
+    int walker = -1;            // walker_kernel (one launch per batch): -1 by batch size, 0 never, 1 whenever possible
     long zerocopy_max = 1l << 20;    // bytes of theta up to which the host entry reads pinned host memory directly
     int no_zerocopy = 0;
     int no_multipole = 0;       // (read when an instrument is added)
@@ -46,7 +44,7 @@ struct Knob { const char* name; const char* env; int is_long; size_t off; };
 const Knob g_knobs[] = {
     VP_KNOB(prep_rpw, "RBVFIT_AMD_PREP_RPW", 0), VP_KNOB(geom, "RBVFIT_AMD_GEOM", 0),
     VP_KNOB(finalize, "RBVFIT_AMD_FINALIZE", 0), VP_KNOB(walker, "RBVFIT_AMD_WALKER", 0),
-    VP_KNOB(walker_max_waves, "RBVFIT_AMD_WALKER_MAX_WAVES", 1), VP_KNOB(zerocopy_max, "RBVFIT_AMD_ZEROCOPY_MAX", 1),
+    VP_KNOB(zerocopy_max, "RBVFIT_AMD_ZEROCOPY_MAX", 1),
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0),
@@ -114,11 +112,18 @@ struct vp_ctx {
     double* d_scratch = nullptr;
     size_t scratch_bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    int last_kind = 0;           // launch structure of the last lnprob batch: 0 prep + tile (+ finalize), 1 walker_kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     struct Span { size_t a, b; int kind; };   // kind: 0 prep, 1 tile, 2 finalize
     std::vector<Span> spans;
+};
+
+struct vp_multi {
+    std::vector<vp_ctx*> ctx;
+    std::mutex mu;
+    std::string err;
 };
 
 namespace {
@@ -278,9 +283,12 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
 
 // walker_kernel: the whole batch in ONE launch (workgroup = walker, wave = tile).  Possible for a single
 // instrument with single-wave tiles, at most 16 of them, whose prior box keeps every line in the fast
-// domain; worth it while the batch is small enough that the prep and finalize launches (4-5 us each) and
-// the dispatch of thousands of one-wave workgroups matter -- large batches keep the one-wave workgroups,
-// which let the hardware refill single wave slots as tiles finish.
+// domain.  A walker's workgroup holds 12 wave slots of one CU for as long as its slowest tile runs, two fit on a
+// CU, so the launch time is a step function of ceil(W / 512 workgroup places): measured on C1 (us per pass,
+// walker kernel / prep + tile + finalize launches) 64: 23.1 / 22.3, 128: 23.1 / 23.6, 256: 23.2 / 25.2,
+// 384: 30.8 / 30.3, 512: 30.9 / 33.1, 768: 46.5 / ~41, 1024: 57 / 48.5.  By default it is therefore used for one
+// layer of >= 40 % of the CUs or a second layer of >= 60 %; larger batches keep the one-wave workgroups, whose slots
+// the hardware refills one by one as tiles finish.
 size_t walker_lds_bytes(const Instrument& in) { return (size_t)in.dev.ntiles * in.lds_bytes + (in.dev.ntiles + 2) * sizeof(double); }
 
 bool walker_applies(const vp_ctx* c, int W) {
@@ -289,7 +297,13 @@ bool walker_applies(const vp_ctx* c, int W) {
     if (in.nwaves != 1 || in.dev.ntiles > vp::WALKER_THREADS_MAX / 64) return false;
     if (in.dev.method == VP_VOIGT_WOFZ && in.needs_generic) return false;
     if (walker_lds_bytes(in) > c->lds_limit) return false;
-    return c->tune.walker == 1 || (long)W * in.dev.ntiles <= c->tune.walker_max_waves;
+    if (c->tune.walker == 1) return true;
+    if (in.dev.NCm > 0) return false;                     // (the cluster-record instance spills to scratch: launches are faster)
+    // a CU holds per_cu walker workgroups at once (24 wave slots / waves per walker, LDS permitting); the batch lies
+    // on the 256 CUs in layers of 256 workgroups and the launch takes as long as the fullest CU's layers
+    const int per_cu = std::max(1, std::min(24 / std::max(1, in.dev.ntiles), (int)(c->lds_limit / walker_lds_bytes(in))));
+    const int layers = (W + 255) / 256, last = W - (layers - 1) * 256;
+    return layers <= std::min(per_cu, 2) && last * 10 >= 256 * (layers == 1 ? 4 : 6);
 }
 
 void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
@@ -306,7 +320,9 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     int tile_off = 0;
     const bool prof = c->profiling;
     size_t m0 = prof ? prof_mark(c, s) : 0;
+    c->last_kind = 0;
     if (walker_applies(c, W)) {
+        c->last_kind = 1;
         launch_walker(c, W, d_theta, d_out, s);
         if (prof) {
             size_t m1 = prof_mark(c, s);
@@ -627,12 +643,10 @@ int vp_lnprob_batch_device(vp_ctx* c, int W, int D, const double* d_theta, doubl
     return enqueue_lnprob(c, W, d_theta, d_out, s);
 }
 
-int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
-    if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
-    int rc = check_batch_args(c, W, D, theta, out);
-    if (rc) return rc;
-    if (W == 0) return VP_OK;
+// (called with c->mu held) host-buffer lnprob in two halves, so that several contexts (vp_multi) can have their
+// batches in flight at once: begin = stage theta + enqueue, end = wait + copy out
+static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta) {
+    int rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     const size_t tb = (size_t)W * D * sizeof(double), ob = (size_t)W * sizeof(double);
@@ -651,9 +665,23 @@ int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
         if ((rc = enqueue_lnprob(c, W, c->d_theta, c->d_out, c->stream))) return rc;
         HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::memcpy(out, h_out, ob);
     return VP_OK;
+}
+static int lnprob_host_end(vp_ctx* c, int W, int D, double* out) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out, c->h_pinned + (size_t)W * D, (size_t)W * sizeof(double));
+    return VP_OK;
+}
+
+int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    int rc = check_batch_args(c, W, D, theta, out);
+    if (rc) return rc;
+    if (W == 0) return VP_OK;
+    if ((rc = lnprob_host_begin(c, W, D, theta))) return rc;
+    return lnprob_host_end(c, W, D, out);
 }
 
 // (called with c->mu held) prep + tile launches that write the (W, P) model flux of one instrument
@@ -1021,6 +1049,94 @@ int vp_profile_read(vp_ctx* c, double* prep_ms, double* tile_ms, double* finaliz
 }
 
 
+// ---- several GPUs from ONE process, no torch / RCCL needed (vp_ctx_create(n_devices, device_ids)) ------
+// Walkers are independent, so a batch is cut into contiguous blocks of ceil(W / G) theta rows, one per context;
+// every context holds the same static data; all blocks are enqueued before any is waited for, and each block's
+// lnprob lands directly in its slice of the caller's output -- the "gather" of this path is G device-to-host
+// copies into one host vector (the RCCL all-gather is for device-resident ensembles, rbvfit_amd/dist.py).
+int vp_multi_create(vp_multi** out, int n_devices, const int* device_ids) {
+    if (!out) return fail(nullptr, VP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_devices <= 0 || !device_ids) return fail(nullptr, VP_EINVAL, "vp_multi_create: n_devices must be positive and device_ids non-NULL");
+    vp_multi* m = new (std::nothrow) vp_multi();
+    if (!m) return fail(nullptr, VP_ENOMEM, "out of host memory");
+    for (int i = 0; i < n_devices; ++i) {
+        vp_ctx* c = nullptr;
+        const int rc = vp_ctx_create(&c, device_ids[i]);
+        if (rc) {                                   // (g_create_error holds the reason)
+            for (vp_ctx* p : m->ctx) vp_ctx_destroy(p);
+            delete m;
+            return rc;
+        }
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return VP_OK;
+}
+
+int vp_multi_destroy(vp_multi* m) {
+    if (!m) return VP_OK;
+    for (vp_ctx* c : m->ctx) vp_ctx_destroy(c);
+    delete m;
+    return VP_OK;
+}
+
+int vp_multi_n_devices(const vp_multi* m) { return m ? (int)m->ctx.size() : 0; }
+vp_ctx* vp_multi_ctx(vp_multi* m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
+const char* vp_multi_last_error(const vp_multi* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+static int multi_fail(vp_multi* m, int i, int rc) {
+    m->err = "device slot " + std::to_string(i) + ": " + vp_last_error(m->ctx[i]);
+    return rc;
+}
+
+int vp_multi_set_bounds(vp_multi* m, int D, const double* lb, const double* ub) {
+    if (!m) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(m->mu);
+    for (size_t i = 0; i < m->ctx.size(); ++i)
+        if (int rc = vp_set_bounds(m->ctx[i], D, lb, ub)) return multi_fail(m, (int)i, rc);
+    return VP_OK;
+}
+
+int vp_multi_add_instrument(vp_multi* m, int P, const double* wave, const double* flux, const double* inv_sigma2,
+                            const double* log_inv_sigma2, int L, const double* lambda0, const double* gamma,
+                            const double* f, const double* zfac, const int32_t* N_idx, const int32_t* b_idx,
+                            const int32_t* v_idx, int K, const double* taps, int lsf_mode, int voigt_method,
+                            int* inst_index) {
+    if (!m) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(m->mu);
+    for (size_t i = 0; i < m->ctx.size(); ++i)
+        if (int rc = vp_add_instrument(m->ctx[i], P, wave, flux, inv_sigma2, log_inv_sigma2, L, lambda0, gamma, f, zfac, N_idx, b_idx,
+                                       v_idx, K, taps, lsf_mode, voigt_method, inst_index))
+            return multi_fail(m, (int)i, rc);
+    return VP_OK;
+}
+
+int vp_multi_lnprob_batch(vp_multi* m, int W, int D, const double* theta, double* out) {
+    if (!m) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(m->mu);
+    if (W < 0 || (W > 0 && (!theta || !out))) { m->err = "vp_multi_lnprob_batch: bad batch"; return VP_EINVAL; }
+    const int G = (int)m->ctx.size();
+    const int per = W > 0 ? (W + G - 1) / G : 0;
+    std::vector<std::unique_lock<std::mutex>> locks;
+    int rc = VP_OK, started = 0;
+    for (int i = 0; i < G && !rc; ++i) {               // every block in flight before any wait
+        const int lo = std::min(i * per, W), n = std::min(lo + per, W) - lo;
+        vp_ctx* c = m->ctx[i];
+        locks.emplace_back(c->mu);
+        ++started;
+        if ((rc = check_batch_args(c, n, D, theta, out))) { multi_fail(m, i, rc); break; }
+        if (n > 0 && (rc = lnprob_host_begin(c, n, D, theta + (size_t)lo * D))) multi_fail(m, i, rc);
+    }
+    for (int i = 0; i < started; ++i) {                 // (also drains the blocks already enqueued when a later one failed)
+        const int lo = std::min(i * per, W), n = std::min(lo + per, W) - lo;
+        if (n <= 0) continue;
+        const int rc2 = lnprob_host_end(m->ctx[i], n, D, out + lo);
+        if (rc2 && !rc) rc = multi_fail(m, i, rc2);
+    }
+    return rc;
+}
+
 void* vp_ctx_stream(const vp_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int vp_num_instruments(const vp_ctx* c) {
@@ -1040,5 +1156,10 @@ int vp_instrument_pixels(const vp_ctx* c, int inst) {
     return c->inst[inst].dev.P;
 }
 int vp_device_id(const vp_ctx* c) { return c ? c->device : -1; }
+int vp_last_launch_kind(const vp_ctx* c) {
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->mu);
+    return c->last_kind;
+}
 
 }  // extern "C"

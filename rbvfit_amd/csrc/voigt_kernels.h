@@ -51,7 +51,7 @@ struct LinesDev {          // static per-instrument line tables (CompiledModelDa
 
 struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of a walker)
     unsigned int* ticket;        // (W) arrival counters, zero between launches
-    const int* tile_off;         // (n_inst + 1) offsets into a walker's partial row
+    const int* tile_off;         // (n_inst + 1) offsets into a walker's partial row; NULL: one instrument, slots [0, total_tiles)
     const double* sum_logw;      // (n_inst) sum of log inv_sigma2
     double* lnprob;              // (W) output
     int n_inst;
@@ -472,10 +472,9 @@ __device__ __forceinline__ void tile_sync() {
 // pass's pixel data): issued first, so that a wave's start-up is one memory round trip instead of
 // four -- and, in walker_kernel, runs under the record preparation.
 struct TilePre { double tap, e2, g[RB], wv[RB]; };
-__device__ __forceinline__ TilePre tile_preload(const InstDev& I, int t, int tid) {
+__device__ __forceinline__ TilePre tile_preload(const InstDev& I, int p0, int nout, int tid) {
     const int lane = tid & 63, wid = tid >> 6;
-    const int p0 = t * I.TP;
-    const int n_eval = min(p0 + I.TP, I.P) - p0 + I.K - 1;
+    const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
     TilePre pre;
     pre.tap = I.kflip[min(tid, I.K - 1)];
@@ -490,20 +489,20 @@ __device__ __forceinline__ TilePre tile_preload(const InstDev& I, int t, int tid
     return pre;
 }
 
-// One tile of one walker: tau -> exp -> LSF -> chi^2 (OUT = 0; returns this WAVE's partial sum, already
-// reduced over its lanes) or model flux written to `out` (OUT = 1 convolved, 2 unconvolved).
+// One tile of one walker -- output pixels [p0, p0 + nout) -- : tau -> exp -> LSF -> chi^2 (OUT = 0; returns this
+// LANE's sum of chi^2 terms) or model flux written to `out` (OUT = 1 convolved, 2 unconvolved).  `first` (uniform):
+// the LDS tables (taps, exp table) are staged; a wave that works through several tiles in a row passes false from
+// its second tile on.  PRE: the tables' entries and the first pass's pixels come from `pre` (tile_preload, issued
+// before the records were needed); without it they are loaded here.
 // `nthreads` threads (tid = 0..nthreads-1, whole waves) share the LDS block `fl`:
 //   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | LSF taps (zero-padded to 8k) | exp table |
 //   per-chunk "line core" masks
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
 // fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
-template <int METHOD, int OUT, bool GENERIC, bool SOLO>
-__device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int t, int w,
-                                            int tid, int nthreads, const TilePre& pre, double* __restrict__ out,
-                                            int out_stride) {
-    const int p0 = t * I.TP;
-    const int p1 = min(p0 + I.TP, I.P);
-    const int nout = p1 - p0;
+template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true>
+__device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
+                                            int tid, int nthreads, const TilePre& pre, bool first,
+                                            double* __restrict__ out, int out_stride) {
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
     const int lane = SOLO ? tid : (tid & 63), wid = SOLO ? 0 : (tid >> 6);     // SOLO: tid IS the lane
@@ -515,10 +514,12 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(etab + EXP_LDS_DOUBLES);
     const int nwords = (I.L + 63) >> 6;                // 64 lines per mask word
     const int nchunks = (n_eval + 63) >> 6;
-    if (tid < Kp) ktap[tid] = tid < I.K ? pre.tap : 0.0;
-    for (int j = tid + TILE_THREADS; j < Kp; j += TILE_THREADS) ktap[j] = j < I.K ? I.kflip[j] : 0.0;
+    if (first) {
+        if (tid < Kp) ktap[tid] = tid < I.K ? (PRE ? pre.tap : I.kflip[tid]) : 0.0;
+        for (int j = tid + TILE_THREADS; j < Kp; j += TILE_THREADS) ktap[j] = j < I.K ? I.kflip[j] : 0.0;
+        if (tid < EXP_LDS_DOUBLES) etab[tid] = PRE ? pre.e2 : g_exp2_64[tid];
+    }
     if (tid < FL_PAD) fl[n_eval + tid] = 0.0;   // what the zero taps multiply must be finite
-    if (tid < EXP_LDS_DOUBLES) etab[tid] = pre.e2;
 
     // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
     //      Each wave owns 3 x 64 consecutive evaluated pixels per pass (RB chunks); lines are the
@@ -528,7 +529,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     bool wave_any = false;                  // did this wave flag any (chunk, line) for phase B?  (wave-uniform)
     for (int base = wid * (64 * RB); base < n_eval; base += TILE_THREADS * RB) {
         double g[RB], wv[RB], tau[RB];
-        if (base == wid * (64 * RB)) {                    // first pass: loaded by tile_preload
+        if (PRE && first && base == wid * (64 * RB)) {    // first pass: loaded by tile_preload
 #pragma unroll
             for (int r = 0; r < RB; ++r) { g[r] = pre.g[r]; wv[r] = pre.wv[r]; tau[r] = 0.0; }
         } else {
@@ -810,7 +811,37 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }
-    return (OUT == 0) ? wave_sum(acc) : 0.0;
+    return acc;
+}
+
+// Publish one partial chi^2 sum of walker w (slot `myslot` of its row); the partials of a walker are then summed in
+// fixed order (bit-identical either way):
+//   mode 0  by a finalize_kernel launch (the kernel boundary orders everything);
+//   mode 1  by the workgroup that draws the walker's last ticket: hand-off by 8-byte agent-scope atomics on both
+//           sides (write-through store, drained before the ticket; L1-bypassing loads after it) --
+//           placement-independent, no fences, and no wave ever waits for another one.
+__device__ __forceinline__ void publish_partial(const FinalizeArgs& F, double* __restrict__ out, int out_stride, int w,
+                                                int myslot, double tile_sum) {
+    double* row = out + (size_t)w * out_stride;
+    if (F.mode == 0) {
+        row[myslot] = tile_sum;
+        return;
+    }
+    __hip_atomic_store(row + myslot, tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int ticket = __hip_atomic_fetch_add(F.ticket + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (unsigned int)(F.total_tiles - 1)) {
+        double total = 0.0;
+        for (int k = 0; k < F.n_inst; ++k) {
+            const int t0 = F.tile_off ? F.tile_off[k] : 0, t1 = F.tile_off ? F.tile_off[k + 1] : F.total_tiles;
+            double sk = 0.0;
+            for (int tt = t0; tt < t1; ++tt)
+                sk += (tt == myslot) ? tile_sum : __hip_atomic_load(row + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total += -0.5 * (sk - F.sum_logw[k]);           // vfit_mcmc.py:309-311
+        }
+        F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
+        __hip_atomic_store(F.ticket + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Tile kernel: grid (W, tiles) x 64/128/256 threads, workgroup = walker x pixel tile; records come from a
@@ -828,17 +859,20 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
     const int t = blockIdx.y, w = blockIdx.x;
     const int oob = (OUT == 0) ? flags[w] : 0;   // tested below, after the first loads are in flight
     const int gen = genflag ? genflag[w] : 0;
-    const TilePre pre = tile_preload(I, t, threadIdx.x);
+    const int p0 = t * I.TP, nout = min(p0 + I.TP, I.P) - p0;
+    const TilePre pre = tile_preload(I, p0, nout, threadIdx.x);
     if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
     if (GENERIC ? (gen == 0) : (gen != 0)) return;   // the other launch owns this walker
     rec_t lcw = as_rec(lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE);
     if (OUT == 2 && I.line_sel == -2) {          // per-line profiles of ALL lines in one launch: grid.z = line, out (W, L, P)
         InstDev J = I;
         J.line_sel = blockIdx.z;
-        tile_work<METHOD, OUT, GENERIC, false>(J, lcw, fl, t, w, threadIdx.x, blockDim.x, pre, out + (size_t)blockIdx.z * I.P, out_stride);
+        tile_work<METHOD, OUT, GENERIC, false>(J, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x, pre, true,
+                                               out + (size_t)blockIdx.z * I.P, out_stride);
         return;
     }
-    const double wsum = tile_work<METHOD, OUT, GENERIC, false>(I, lcw, fl, t, w, threadIdx.x, blockDim.x, pre, out, out_stride);
+    const double wsum = wave_sum(tile_work<METHOD, OUT, GENERIC, false>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x, pre, true,
+                                                                        out, out_stride));
     if (OUT == 0) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
         double* red = fl + I.span + FL_PAD;
@@ -847,33 +881,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
         if (threadIdx.x == 0) {
             double tile_sum = red[0];
             for (int k = 1; k < nwaves; ++k) tile_sum += red[k];
-            // Publish this tile's partial; the partials of a walker are then summed in fixed order
-            // (bit-identical either way):
-            //   mode 0  by a finalize_kernel launch (the kernel boundary orders everything);
-            //   mode 1  by the workgroup that draws the walker's last ticket: hand-off by 8-byte agent-scope
-            //           atomics on both sides (write-through store, drained before the ticket; L1-bypassing
-            //           loads after it) -- placement-independent, no fences, and no wave ever waits for
-            //           another one.
-            double* row = out + (size_t)w * out_stride;
-            const int myslot = out_offset + t;
-            if (F.mode == 0) {
-                row[myslot] = tile_sum;
-                return;
-            }
-            __hip_atomic_store(row + myslot, tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned int ticket = __hip_atomic_fetch_add(F.ticket + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ticket == (unsigned int)(F.total_tiles - 1)) {
-                double total = 0.0;
-                for (int k = 0; k < F.n_inst; ++k) {
-                    double sk = 0.0;
-                    for (int tt = F.tile_off[k]; tt < F.tile_off[k + 1]; ++tt)
-                        sk += (tt == myslot) ? tile_sum : __hip_atomic_load(row + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    total += -0.5 * (sk - F.sum_logw[k]);           // vfit_mcmc.py:309-311
-                }
-                F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
-                __hip_atomic_store(F.ticket + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            publish_partial(F, out, out_stride, w, out_offset + t, tile_sum);
         }
     }
 }
@@ -988,7 +996,8 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
             if (k < T.NCm) prep_cluster(th, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
         }
     }
-    const TilePre pre = tile_preload(I, wid, lane);     // in flight while the stores drain
+    const int p0 = wid * I.TP, nout = min(p0 + I.TP, I.P) - p0;
+    const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (red[nw] != 0.0) {                          // out-of-bounds walker: the model is not evaluated
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
     // can be scheduled above it
     unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
     asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-    const double wsum = tile_work<METHOD, 0, false, true>(I, (rec_t)pq, fl, wid, w, lane, 64, pre, nullptr, 0);
+    const double wsum = wave_sum(tile_work<METHOD, 0, false, true>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, true, nullptr, 0));
     if (lane == 0) red[wid] = wsum;
     __syncthreads();
     if (tid == 0) {

@@ -268,6 +268,13 @@ class Engine:
         return dict(pos=pos, lnprob=lp, chain=chain, chain_lnprob=clp, mu=c_mu.value, tune=bool(c_tune.value),
                     mu_history=hist[:nsteps], n_evals=int(c_ne.value))
 
+    @property
+    def last_launch_kind(self) -> str:
+        """'walker' when the last lnprob batch ran as ONE walker_kernel launch, else 'tiles' (prep + tile
+        (+ finalize) launches)."""
+        self._guard()
+        return "walker" if self._lib.vp_last_launch_kind(self._ctx) == 1 else "tiles"
+
     # -- per-kernel timing (HIP events on the launch stream) ------------------------------------
     def profile_enable(self, on: bool = True):
         self._guard()
@@ -279,3 +286,101 @@ class Engine:
         a, b, c_, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
         self._check(self._lib.vp_profile_read(self._ctx, C.byref(a), C.byref(b), C.byref(c_), C.byref(n)))
         return dict(prep_ms=a.value, tile_ms=b.value, finalize_ms=c_.value, n_tile_launches=n.value)
+
+
+class MultiEngine:
+    """Several GPUs from ONE process through ``vp_multi_*`` (no torch, no RCCL): one context per entry of
+    ``device_ids`` (a device may appear more than once), identical static data on each, and ``lnprob``
+    shards the walker rows in contiguous blocks of ceil(W / n) -- ``rbvfit_amd.dist.shard_bounds`` --
+    with every block in flight before any is waited for.  The torch-free counterpart of
+    ``rbvfit_amd.dist.ShardedPosterior`` (which is one process per GPU + an RCCL all-gather)."""
+
+    def __init__(self, device_ids: Sequence[int]):
+        self._lib = L.load()
+        self._m = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        rc = self._lib.vp_multi_create(C.byref(self._m), len(device_ids), ids)
+        if rc != L.VP_OK:
+            msg = self._lib.vp_multi_last_error(None)
+            raise L.RbvfitAmdError(rc, msg.decode() if msg else "vp_multi_create failed")
+        self._pid = os.getpid()
+        self.device_ids = [int(d) for d in device_ids]
+        self.ndim = 0
+
+    def close(self):
+        if getattr(self, "_m", None) and self._m.value and os.getpid() == self._pid:
+            self._lib.vp_multi_destroy(self._m)
+        self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _guard(self):
+        if os.getpid() != self._pid:
+            raise RuntimeError("rbvfit_amd.MultiEngine used in a forked child (a HIP context does not survive fork())")
+        if not self._m.value:
+            raise RuntimeError("rbvfit_amd.MultiEngine is closed")
+
+    def _check(self, rc):
+        if rc != L.VP_OK:
+            msg = self._lib.vp_multi_last_error(self._m)
+            raise L.RbvfitAmdError(rc, msg.decode() if msg else "unknown error")
+
+    @property
+    def n_devices(self) -> int:
+        return int(self._lib.vp_multi_n_devices(self._m))
+
+    def set_option(self, name: str, value: int):
+        self._guard()
+        for i in range(self.n_devices):
+            ctx = C.c_void_p(self._lib.vp_multi_ctx(self._m, i))
+            L.check(self._lib, ctx, self._lib.vp_set_option(ctx, str(name).encode(), int(value)))
+
+    def set_bounds(self, lb, ub):
+        self._guard()
+        lb, ub = _f64(lb).ravel(), _f64(ub).ravel()
+        if lb.shape != ub.shape:
+            raise ValueError("lb and ub must have the same length")
+        self._check(self._lib.vp_multi_set_bounds(self._m, lb.size, _dp(lb), _dp(ub)))
+        self.ndim = lb.size
+
+    def add_instrument(self, wave, flux, inv_sigma2, log_inv_sigma2, lambda0, gamma, f, zfac,
+                       N_idx, b_idx, v_idx, taps=None, lsf_mode=L.LSF_NONE, voigt_method=L.VOIGT_WOFZ) -> int:
+        self._guard()
+        wave, flux, w, lw = _f64(wave), _f64(flux), _f64(inv_sigma2), _f64(log_inv_sigma2)
+        if not (wave.ndim == 1 and wave.shape == flux.shape == w.shape == lw.shape):
+            raise ValueError("wave, flux, inv_sigma2 and log_inv_sigma2 must be 1-D arrays of equal length")
+        lam, gam, fo, zf = _f64(lambda0), _f64(gamma), _f64(f), _f64(zfac)
+        ni = np.ascontiguousarray(N_idx, dtype=np.int32)
+        bi = np.ascontiguousarray(b_idx, dtype=np.int32)
+        vi = np.ascontiguousarray(v_idx, dtype=np.int32)
+        if taps is None or lsf_mode == L.LSF_NONE or len(taps) == 0:
+            K, tp, lsf_mode = 0, None, L.LSF_NONE
+        else:
+            t = _f64(taps)
+            K, tp = t.size, _dp(t)
+        idx = C.c_int(-1)
+        self._check(self._lib.vp_multi_add_instrument(
+            self._m, wave.size, _dp(wave), _dp(flux), _dp(w), _dp(lw), lam.size, _dp(lam), _dp(gam),
+            _dp(fo), _dp(zf), _ip(ni), _ip(bi), _ip(vi), K, tp, int(lsf_mode), int(voigt_method), C.byref(idx)))
+        return idx.value
+
+    def lnprob(self, theta) -> np.ndarray:
+        self._guard()
+        th = _f64(theta)
+        if th.ndim == 1:
+            th = th[None, :]
+        if th.ndim != 2 or th.shape[1] != self.ndim:
+            raise ValueError(f"theta must have shape (W, {self.ndim}) or ({self.ndim},); got {np.shape(theta)}")
+        out = np.empty(th.shape[0], dtype=np.float64)
+        self._check(self._lib.vp_multi_lnprob_batch(self._m, th.shape[0], th.shape[1], _dp(th), _dp(out)))
+        return out

@@ -217,3 +217,43 @@ def test_lnprob_torch_orders_with_default_and_side_streams():
         with pytest.raises(ValueError):
             eng.lnprob_torch(base.float())
         assert eng.stream_handle != 0
+
+
+def test_multi_context_sharding_from_one_process():
+    """vp_multi_* (one process, several device contexts, no torch/RCCL): the batch is cut into
+    contiguous blocks of ceil(W/G) rows, every block is enqueued before any is waited for, and the results land
+    in the caller's vector in walker order.  The box has one GPU, so the same device is listed two and three
+    times -- the sharding, the ragged cases (W < G, W not divisible) and the error path are what is exercised."""
+    import rbvfit_amd
+    from rbvfit_amd.dist import shard_bounds
+    from helpers import fixture_instruments
+    z = load_golden("c0_mgii")
+    with engine_from_fixture(z) as one:
+        ref = one.lnprob(z["thetas"])
+    for ids in ([0, 0], [0, 0, 0]):
+        with rbvfit_amd.MultiEngine(ids) as m:
+            assert m.n_devices == len(ids)
+            m.set_bounds(z["lb"], z["ub"])
+            for inst in fixture_instruments(z):
+                g = lambda k: z[f"{inst}__{k}"]
+                m.add_instrument(g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"), g("f"),
+                                 g("zfac"), g("N_idx"), g("b_idx"), g("v_idx"), taps=g("taps"), lsf_mode=int(g("lsf_mode")),
+                                 voigt_method=int(g("voigt_method")))
+            for W in (len(z["thetas"]), 7, 2, 1):
+                got = m.lnprob(z["thetas"][:W])
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref[:W]))
+                fin = np.isfinite(ref[:W])
+                np.testing.assert_allclose(got[fin], ref[:W][fin], rtol=1e-13, atol=0)
+                # each block is exactly what a single context returns for those rows
+                with engine_from_fixture(z) as one:
+                    for r in range(len(ids)):
+                        lo, hi = shard_bounds(W, len(ids), r)
+                        if hi > lo:
+                            assert np.array_equal(got[lo:hi], one.lnprob(z["thetas"][lo:hi]), equal_nan=True)
+            import ctypes as C
+            dp = C.POINTER(C.c_double)
+            bad, buf = np.zeros((3, 5)), np.empty(3)
+            with pytest.raises(rbvfit_amd.RbvfitAmdError, match="device slot 0.*D=5"):       # wrong D: the failing slot is named
+                m._check(m._lib.vp_multi_lnprob_batch(m._m, 3, 5, bad.ctypes.data_as(dp), buf.ctypes.data_as(dp)))
+    with pytest.raises(rbvfit_amd.RbvfitAmdError):
+        rbvfit_amd.MultiEngine([0, 99])
