@@ -83,16 +83,18 @@ struct InstDev {
 // ---------------------------------------------------------------------------------------------
 // Multipole record of a cluster (same 64-double stride as a line record):
 //   [0] A_c  [1] B_c  (y = A_c/wave - B_c)
-//   [2..5] Y_0..Y_3: tier k of the expansion may be used where every |y| >= Y_k (inf: never)
-//   [6..20] Q_2..Q_16 :  tau_cluster(y) = sum_j Q_j y^-j
+//   [2..6] Y_0..Y_4: tier k of the expansion may be used where every |y| >= Y_k (inf: never)
+//   [7..32] Q_2..Q_27 :  tau_cluster(y) = sum_j Q_j y^-j
 // Tiers (member |x| floor X_k, ratio floor |y|/max|delta| R_k, terms J_k): the farther the pixels, the
 // fewer terms of the same series are needed (worst relative truncation error over random clusters of
-// 2..8 members against scipy's wofz: 4e-13, 8e-14, 9e-14, 1e-14 -- scripts/multipole_check.py).
-constexpr int MP_A = 0, MP_B = 1, MP_Y0 = 2, MP_NTIER = 4, MP_Q0 = 6, MP_NQ = 15, MP_JMIN = 2;
+// 2..8 members against scipy's wofz: 2e-14, 4e-13, 8e-14, 9e-14, 1e-14 -- scripts/multipole_check.py).
+// The nearest tier (ratio 1/4, 26 terms) is what brings the expansion right up to the 6-term radius of its
+// members (|x| >= 30) for clusters as wide as 7.5 Doppler widths: 26 FMAs per chunk instead of n_members x ~25.
+constexpr int MP_A = 0, MP_B = 1, MP_Y0 = 2, MP_NTIER = 5, MP_Q0 = 7, MP_NQ = 26, MP_JMIN = 2;
 constexpr int MP_MWING = 6;      // asymptotic terms kept per member (valid for |x| >= 30)
-constexpr double MP_X[MP_NTIER] = {30.0, 100.0, 500.0, 3000.0};
-constexpr double MP_R[MP_NTIER] = {10.0, 30.0, 100.0, 1000.0};
-constexpr int MP_J0 = 15, MP_J1 = 10, MP_J2 = 7, MP_J3 = 5;
+constexpr double MP_X[MP_NTIER] = {30.0, 30.0, 100.0, 500.0, 3000.0};
+constexpr double MP_R[MP_NTIER] = {4.0, 10.0, 30.0, 100.0, 1000.0};
+constexpr int MP_J0 = 26, MP_J1 = 15, MP_J2 = 10, MP_J3 = 7, MP_J4 = 5;
 
 struct WingTable { double c[NWING][NWING]; };
 constexpr WingTable make_wing_table() {
@@ -160,12 +162,10 @@ __device__ __forceinline__ void fill_record(double* __restrict__ rec, double T, 
 // (voigt_model.py:192-200) and _vectorized_voigt_tau's per-line constants (:142-149) operation by
 // operation (the file is compiled with -ffp-contract=off, so nothing here is fused).
 struct LineScalars { double d, freq0, ibf, a, Tl, cfd, Ax, Bx; };
-__device__ __forceinline__ LineScalars line_scalars(const double* __restrict__ th, const LinesDev& T, int l) {
+__device__ __forceinline__ LineScalars line_scalars_nbv(double thN, double b, double v, const LinesDev& T, int l) {
     LineScalars s;
     const double lam0 = T.lambda0[l], gam = T.gamma[l], fo = T.f[l], zf = T.zfac[l];
-    const double N = exp10(th[T.N_idx[l]]);            // :192  (10**theta; <= 1 ulp, only scales tau)
-    const double b = th[T.b_idx[l]];                   // :193
-    const double v = th[T.v_idx[l]];                   // :194
+    const double N = exp10(thN);                       // :192  (10**theta; <= 1 ulp, only scales tau)
     // quantities that enter x are formed with the reference's operations and roundings ...
     const double z_total = zf * (1.0 + v / C_KMS) - 1.0;   // :200
     s.d = 1.0 + z_total;                               // :204
@@ -180,6 +180,9 @@ __device__ __forceinline__ LineScalars line_scalars(const double* __restrict__ t
     s.Ax = s.cfd * s.ibf;
     s.Bx = s.freq0 * s.ibf;
     return s;
+}
+__device__ __forceinline__ LineScalars line_scalars(const double* __restrict__ th, const LinesDev& T, int l) {
+    return line_scalars_nbv(th[T.N_idx[l]], th[T.b_idx[l]], th[T.v_idx[l]], T, l);     // :192-194
 }
 
 // Multipole expansion of one cluster (the components of one transition) about its centre, for the
@@ -454,6 +457,49 @@ __device__ __forceinline__ Eager load_eager(rec_t rec) {
     return e;
 }
 
+// Phase B of one flagged 64-pixel chunk c of a tile (its raw tau is in the tile's LDS window `fl`, the lines to add
+// in its mask words `cm`): core series for every lane (no divergence), 14-term wing value for lanes of a mixed
+// chunk beyond the core radius, then exp.  `daw` / `etab`: the Dawson and exp tables in LDS.
+template <bool GENERIC>
+__device__ __forceinline__ void core_chunk(const InstDev& I, rec_t lcw, double* __restrict__ fl,
+                                           const unsigned long long* __restrict__ cm, int nwords, int q0, int n_eval, int c,
+                                           int lane, const double* __restrict__ daw, const double* __restrict__ etab) {
+    const int i = c * 64 + lane;
+    const int ic = min(i, n_eval - 1);
+    const int q = min(max(q0 + ic, 0), I.P - 1);
+    const double gq = I.ginv[q], wq = I.wave[q];
+    double tau = fl[ic];
+    for (int wd = 0; wd < nwords; ++wd) {
+        unsigned long long m = cm[c * nwords + wd];
+        {   // scalarise (mind the sign: readfirstlane returns int)
+            const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)m);
+            const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
+            m = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
+        }
+        while (m) {
+            const int l = (wd << 6) + __builtin_ctzll(m);
+            m &= m - 1;
+            rec_t rec = lcw + (size_t)l * LC_STRIDE;
+            const int mode = rec_int(rec, LC_MODE, 0);
+            if (mode != 0) {
+                if (GENERIC) tau += cold_line_tau(wq, gq, rec);
+                else tau = __builtin_nan("");          // poisoned line (non-finite constants)
+                continue;
+            }
+            const double xf = faithful_x(wq, gq, rec);
+            const double xa = fabs(xf);
+            const int nodd = rec_int(rec, LC_MODE, 1);
+            double h = rec[LC_T] * core_taylor_H_lds(xf, rec[LC_Y], rec[LC_EA2], nodd, daw, etab);
+            if (__ballot(xa >= X_CORE) != 0ull) {
+                const double rw = wing_tau<NWING>(xf, rec + LC_K0);
+                h = (xa >= X_CORE) ? rw : h;
+            }
+            tau += h;
+        }
+    }
+    if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg_tab(tau, etab);   // NaN survives (poisoned lines)
+}
+
 // Synchronisation among the threads that share one tile.  SOLO: the tile belongs to ONE wave of a
 // larger workgroup (walker_kernel) and must not wait for the others: the LDS operations of a wave
 // execute in program order, so only the compiler has to be kept from reordering them.
@@ -529,7 +575,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     bool wave_any = false;                  // did this wave flag any (chunk, line) for phase B?  (wave-uniform)
     for (int base = wid * (64 * RB); base < n_eval; base += TILE_THREADS * RB) {
         double g[RB], wv[RB], tau[RB];
-        if (PRE && first && base == wid * (64 * RB)) {    // first pass: loaded by tile_preload
+        if (PRE && base == wid * (64 * RB)) {             // first pass: loaded by tile_preload
 #pragma unroll
             for (int r = 0; r < RB; ++r) { g[r] = pre.g[r]; wv[r] = pre.wv[r]; tau[r] = 0.0; }
         } else {
@@ -561,7 +607,8 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                         // A, B and the four tier radii arrive with ONE scalar load (no load behind a tier decision
                         // except the Q_j themselves)
                         const double Ac = mrec[MP_A], Bc = mrec[MP_B];
-                        const double y0 = mrec[MP_Y0], y1 = mrec[MP_Y0 + 1], y2 = mrec[MP_Y0 + 2], y3 = mrec[MP_Y0 + 3];
+                        const double y0 = mrec[MP_Y0], y1 = mrec[MP_Y0 + 1], y2 = mrec[MP_Y0 + 2], y3 = mrec[MP_Y0 + 3],
+                                     y4 = mrec[MP_Y0 + 4];
                         double y[RB];
 #pragma unroll
                         for (int r = 0; r < RB; ++r) y[r] = __builtin_fma(Ac, g[r], -Bc);
@@ -569,15 +616,18 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
 #pragma unroll
                         for (int r = 1; r < RB; ++r) ym = fmin(ym, fabs(y[r]));
                         const bool far0 = __ballot(!(ym >= y0)) == 0ull;      // every lane far enough (NaN counts as near)
-                        const bool far1 = VP_NONE_BELOW(ym, y1), far2 = VP_NONE_BELOW(ym, y2), far3 = VP_NONE_BELOW(ym, y3);
+                        const bool far1 = VP_NONE_BELOW(ym, y1), far2 = VP_NONE_BELOW(ym, y2), far3 = VP_NONE_BELOW(ym, y3),
+                                   far4 = VP_NONE_BELOW(ym, y4);
                         if (far0) {
-                            if (far1) {
-                                if (far2) {
-                                    if (far3) multipole_rb<MP_J3>(y, mrec + MP_Q0, tau);
-                                    else multipole_rb<MP_J2>(y, mrec + MP_Q0, tau);
+                            if (far2) {
+                                if (far3) {
+                                    if (far4) multipole_rb<MP_J4>(y, mrec + MP_Q0, tau);
+                                    else multipole_rb<MP_J3>(y, mrec + MP_Q0, tau);
                                 } else {
-                                    multipole_rb<MP_J1>(y, mrec + MP_Q0, tau);
+                                    multipole_rb<MP_J2>(y, mrec + MP_Q0, tau);
                                 }
+                            } else if (far1) {
+                                multipole_rb<MP_J1>(y, mrec + MP_Q0, tau);
                             } else {
                                 multipole_rb<MP_J0>(y, mrec + MP_Q0, tau);
                             }
@@ -678,10 +728,9 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     tile_sync<SOLO>();
 
     // ---- phase B: line cores.  The flagged chunks of the tile are dealt round-robin to the
-    //      waves (balanced whatever their position), each chunk finished by one wave: core series
-    //      for every lane (no divergence), 14-term wing value for lanes of a mixed chunk beyond the
-    //      core radius, then exp.  Single instance of the core code keeps the hot loop's registers
-    //      low.  All control flow here is wave-uniform, so lane-held records stay readable.
+    //      waves (balanced whatever their position), each chunk finished by one wave (core_chunk).
+    //      Single instance of the core code keeps the hot loop's registers low.  All control flow
+    //      here is wave-uniform, so lane-held records stay readable.
     if (METHOD == 0) {
         // anything to do?  A single wave knows from its own registers (and skips the whole phase, mask
         // scan included: ~1 us of a 10 us tile without line cores); wider workgroups scan the masks
@@ -707,40 +756,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                 }
                 if (__builtin_amdgcn_readfirstlane(any) == 0u) continue;
                 if ((kth++ & (nwaves - 1)) != wid) continue;
-                const int i = c * 64 + lane;
-                const int ic = min(i, n_eval - 1);
-                const int q = min(max(q0 + ic, 0), I.P - 1);
-                const double gq = I.ginv[q], wq = I.wave[q];
-                double tau = fl[ic];
-                for (int wd = 0; wd < nwords; ++wd) {
-                    unsigned long long m = cmask[c * nwords + wd];
-                    {   // scalarise (mind the sign: readfirstlane returns int)
-                        const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)m);
-                        const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
-                        m = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
-                    }
-                    while (m) {
-                        const int l = (wd << 6) + __builtin_ctzll(m);
-                        m &= m - 1;
-                        rec_t rec = lcw + (size_t)l * LC_STRIDE;
-                        const int mode = rec_int(rec, LC_MODE, 0);
-                        if (mode != 0) {
-                            if (GENERIC) tau += cold_line_tau(wq, gq, rec);
-                            else tau = __builtin_nan("");          // poisoned line (non-finite constants)
-                            continue;
-                        }
-                        const double xf = faithful_x(wq, gq, rec);
-                        const double xa = fabs(xf);
-                        const int nodd = rec_int(rec, LC_MODE, 1);
-                        double h = rec[LC_T] * core_taylor_H_lds(xf, rec[LC_Y], rec[LC_EA2], nodd, daw, etab);
-                        if (__ballot(xa >= X_CORE) != 0ull) {
-                            const double rw = wing_tau<NWING>(xf, rec + LC_K0);
-                            h = (xa >= X_CORE) ? rw : h;
-                        }
-                        tau += h;
-                    }
-                }
-                if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg_tab(tau, etab);   // NaN survives (poisoned lines)
+                core_chunk<GENERIC>(I, lcw, fl, cmask, nwords, q0, n_eval, c, lane, daw, etab);
             }
         }
         tile_sync<SOLO>();
@@ -894,11 +910,20 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 // coefficients -- the same operations in the same order as fill_record, so the record is bit-identical
 // to prep_lines_kernel's), slots 14 and 15 store the scalars.  ~100 instructions per wave instead of
 // ~350 per record lane: this sits on the critical path of the walker's workgroup.
-__device__ __forceinline__ void prep_record_lanes(const double* __restrict__ th, const LinesDev& T, int l0,
+__device__ __forceinline__ void prep_record_lanes(const double* __restrict__ th, int D, const LinesDev& T, int l0,
                                                   double* __restrict__ lcw, int lane) {
-    const int j = lane >> 4, slot = lane & 15, l = l0 + j;
-    if (l >= T.L) return;
-    const LineScalars s = line_scalars(th, T, l);
+    const int j = lane >> 4, slot = lane & 15, l = min(l0 + j, T.L - 1);
+    // theta row and index tables are fetched side by side (the row lives across the lanes and the three
+    // parameters of the line are picked with lane shuffles): one memory round trip instead of index -> theta
+    LineScalars s;
+    if (D <= 64) {
+        const double thv = th[min(lane, D - 1)];
+        const int iN = T.N_idx[l], ib = T.b_idx[l], iv = T.v_idx[l];
+        s = line_scalars_nbv(__shfl(thv, iN, 64), __shfl(thv, ib, 64), __shfl(thv, iv, 64), T, l);
+    } else {
+        s = line_scalars(th, T, l);
+    }
+    if (l0 + j >= T.L) return;
     const bool xok = (fabs(s.Ax) <= 1.79e308) && (fabs(s.Bx) <= 1.79e308);
     const double Tl = xok ? s.Tl : __builtin_nan(""), a = s.a;
     double* __restrict__ rec = lcw + (size_t)l * LC_STRIDE;
@@ -990,7 +1015,7 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
             const bool any = __ballot(oob != 0) != 0ull;
             if (lane == 0) red[nw] = any ? 1.0 : 0.0;
         } else if (task <= ngrp) {
-            prep_record_lanes(th, T, (task - 1) * 4, lcw, lane);
+            prep_record_lanes(th, A.D, T, (task - 1) * 4, lcw, lane);
         } else if (CLUSTERS) {
             const int k = (task - 1 - ngrp) * 64 + lane;
             if (k < T.NCm) prep_cluster(th, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
@@ -998,6 +1023,12 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
     }
     const int p0 = wid * I.TP, nout = min(p0 + I.TP, I.P) - p0;
     const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
+    {   // the wave's LDS tables (taps, exp table) are staged while it waits for the records anyway
+        double* __restrict__ ktap = fl + I.span + FL_PAD + 4 + DAW_LDS_DOUBLES;
+        const int Kp = (I.K + 7) & ~7;
+        for (int j = lane; j < Kp; j += 64) ktap[j] = j < I.K ? I.kflip[j] : 0.0;
+        ktap[Kp + lane] = g_exp2_64[lane];                     // etab = ktap + Kp, EXP_LDS_DOUBLES = 64 entries
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (red[nw] != 0.0) {                          // out-of-bounds walker: the model is not evaluated
@@ -1008,7 +1039,7 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
     // can be scheduled above it
     unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
     asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-    const double wsum = wave_sum(tile_work<METHOD, 0, false, true>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, true, nullptr, 0));
+    const double wsum = wave_sum(tile_work<METHOD, 0, false, true>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0));
     if (lane == 0) red[wid] = wsum;
     __syncthreads();
     if (tid == 0) {

@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU box: walker_kernel (one launch per batch) vs prep + tile + finalize launches on C1.
-# Usage: scripts/exp_walker.sh <out-file> ; each line: label W evals/s us/step tile_us prep_us fin_us
+# GPU box: walker_kernel (one launch per batch; plain and with cooperative line cores) vs prep + tile + finalize launches on C1.
+# Usage: scripts/exp_walker.sh <out-file> ; each line: label W evals/s us/step kernel_us prep_us fin_us
 OUT=${1:-gpurun_out/exp_walker.txt}
 : > $OUT
 run() {
@@ -18,3 +18,4 @@ print('$label', d['config']['walkers_per_gpu'], round(d['value']), round(1e3*d['
 WS="${WS:-64 128 256 512 1024 2048 8192}"
 run launches RBVFIT_AMD_WALKER=0 -- $WS
 run walker RBVFIT_AMD_WALKER=1 -- $WS
+run walker_coop RBVFIT_AMD_WALKER=1 RBVFIT_AMD_WALKER_COOP=1 -- $WS
