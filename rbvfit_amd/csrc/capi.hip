@@ -294,7 +294,7 @@ size_t walker_lds_bytes(const Instrument& in) { return (size_t)in.dev.ntiles * i
 bool walker_applies(const vp_ctx* c, int W) {
     if (c->tune.walker == 0 || c->inst.size() != 1) return false;
     const Instrument& in = c->inst[0];
-    if (in.nwaves != 1 || in.dev.ntiles > vp::WALKER_THREADS_MAX / 64) return false;
+    if (in.nwaves != 1 || in.dev.ntiles > vp::WALKER_THREADS_MAX / 64 || c->D > 64) return false;
     if (in.dev.method == VP_VOIGT_WOFZ && in.needs_generic) return false;
     if (walker_lds_bytes(in) > c->lds_limit) return false;
     if (c->tune.walker == 1) return true;
@@ -309,11 +309,23 @@ bool walker_applies(const vp_ctx* c, int W) {
 void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
     const Instrument& in = c->inst[0];
     vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, in.sum_logw, c->D, (int)(in.lds_bytes / sizeof(double))};
+    const vp::StretchArgs none{};
     const dim3 grid(W), block(64 * in.dev.ntiles);
     const size_t lds = walker_lds_bytes(in);
-    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false>), grid, block, lds, s, in.dev, in.lines, a);
-    else if (in.dev.NCm > 0) hipLaunchKernelGGL((vp::walker_kernel<0, true>), grid, block, lds, s, in.dev, in.lines, a);
-    else hipLaunchKernelGGL((vp::walker_kernel<0, false>), grid, block, lds, s, in.dev, in.lines, a);
+    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, false>), grid, block, lds, s, in.dev, in.lines, a, none);
+    else if (in.dev.NCm > 0) hipLaunchKernelGGL((vp::walker_kernel<0, true, false>), grid, block, lds, s, in.dev, in.lines, a, none);
+    else hipLaunchKernelGGL((vp::walker_kernel<0, false, false>), grid, block, lds, s, in.dev, in.lines, a, none);
+}
+
+// One stretch-move half-step of the active half (nS walkers) as ONE launch: proposal, lnprob and accept/reject inside
+// each walker's workgroup (walker_kernel<.., SAMPLER = true>).
+void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStream_t s) {
+    const Instrument& in = c->inst[0];
+    vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc, nullptr, in.sum_logw, c->D, (int)(in.lds_bytes / sizeof(double))};
+    const dim3 grid(nS), block(64 * in.dev.ntiles);
+    const size_t lds = walker_lds_bytes(in);
+    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, true>), grid, block, lds, s, in.dev, in.lines, a, st);
+    else hipLaunchKernelGGL((vp::walker_kernel<0, false, true>), grid, block, lds, s, in.dev, in.lines, a, st);
 }
 
 int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
@@ -438,8 +450,9 @@ int vp_ctx_create(vp_ctx** out, int device_id) {
     int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds_max > 0)
         c->lds_limit = (size_t)lds_max;
-    for (const void* f : {(const void*)vp::walker_kernel<0, false>, (const void*)vp::walker_kernel<0, true>,
-                          (const void*)vp::walker_kernel<1, false>,
+    for (const void* f : {(const void*)vp::walker_kernel<0, false, false>, (const void*)vp::walker_kernel<0, true, false>,
+                          (const void*)vp::walker_kernel<1, false, false>, (const void*)vp::walker_kernel<0, false, true>,
+                          (const void*)vp::walker_kernel<1, false, true>,
                           (const void*)vp::tile_kernel<0, 0, false>, (const void*)vp::tile_kernel<0, 0, true>,
                           (const void*)vp::tile_kernel<0, 1, false>, (const void*)vp::tile_kernel<0, 1, true>,
                           (const void*)vp::tile_kernel<0, 2, false>, (const void*)vp::tile_kernel<0, 2, true>,
@@ -815,6 +828,9 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
         if (h_nan0) return fail(c, VP_ENAN, "vp_stretch_run: the initial lnprob holds NaN (Probability function returned NaN)");
     }
     const int thr = 64;
+    // whole half-step in one launch (proposal, lnprob, accept inside each walker's workgroup) where the walker kernel
+    // applies to a half-ensemble batch and the instrument has no cluster records
+    const bool one_launch = !c->tune.no_fused_accept && c->tune.walker != 0 && walker_applies(c, half) && c->inst[0].dev.NCm == 0;
     const bool fuse = W <= 1024 && !c->tune.no_fused_accept;   // accept + next proposal in one launch
     const int wthr = ((W + 63) / 64) * 64;
     bool have_prop = false;                                   // is the proposal of the coming pass already enqueued?
@@ -824,6 +840,15 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
             const uint64_t step = step0 + (uint64_t)(done + it);
             for (int h = 0; h < 2; ++h) {
                 const int s0 = h ? half : 0, c0 = h ? 0 : half;
+                if (one_launch) {
+                    vp::StretchArgs sa{};
+                    sa.pos = d_pos; sa.lp = d_lp; sa.nacc = d_nacc; sa.nanflag = d_nan;
+                    sa.chain_pos = chain ? d_chain + (size_t)it * W * D : (double*)nullptr;
+                    sa.chain_lp = chain ? d_chain + chunk * (size_t)W * D + (size_t)it * W : (double*)nullptr;
+                    sa.a = a; sa.seed = seed; sa.step = step; sa.s0 = s0; sa.c0 = c0; sa.nC = half; sa.half = h;
+                    launch_walker_stretch(c, half, sa, s);
+                    continue;
+                }
                 if (!have_prop)
                     hipLaunchKernelGGL(vp::stretch_propose_kernel, dim3((half + thr - 1) / thr), dim3(thr), 0, s, d_pos, D, s0,
                                        half, c0, half, a, seed, step, h, d_prop, d_zz);

@@ -28,6 +28,7 @@
 // No float atomics anywhere: results are bit-reproducible.
 #pragma once
 #include "voigt_device.h"
+#include "sampler_kernels.h"   // Philox draws + the stretch move's arithmetic (walker_kernel's sampler form)
 
 namespace vp {
 
@@ -910,19 +911,12 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 // coefficients -- the same operations in the same order as fill_record, so the record is bit-identical
 // to prep_lines_kernel's), slots 14 and 15 store the scalars.  ~100 instructions per wave instead of
 // ~350 per record lane: this sits on the critical path of the walker's workgroup.
-__device__ __forceinline__ void prep_record_lanes(const double* __restrict__ th, int D, const LinesDev& T, int l0,
-                                                  double* __restrict__ lcw, int lane) {
+__device__ __forceinline__ void prep_record_lanes(double thv, const LinesDev& T, int l0, double* __restrict__ lcw, int lane) {
     const int j = lane >> 4, slot = lane & 15, l = min(l0 + j, T.L - 1);
-    // theta row and index tables are fetched side by side (the row lives across the lanes and the three
-    // parameters of the line are picked with lane shuffles): one memory round trip instead of index -> theta
-    LineScalars s;
-    if (D <= 64) {
-        const double thv = th[min(lane, D - 1)];
-        const int iN = T.N_idx[l], ib = T.b_idx[l], iv = T.v_idx[l];
-        s = line_scalars_nbv(__shfl(thv, iN, 64), __shfl(thv, ib, 64), __shfl(thv, iv, 64), T, l);
-    } else {
-        s = line_scalars(th, T, l);
-    }
+    // the theta row lives across the lanes (thv = theta[lane], D <= 64) and the three parameters of the line are
+    // picked with lane shuffles: the index tables are fetched beside it, one memory round trip instead of index -> theta
+    const int iN = T.N_idx[l], ib = T.b_idx[l], iv = T.v_idx[l];
+    const LineScalars s = line_scalars_nbv(__shfl(thv, iN, 64), __shfl(thv, ib, 64), __shfl(thv, iv, 64), T, l);
     if (l0 + j >= T.L) return;
     const bool xok = (fabs(s.Ax) <= 1.79e308) && (fabs(s.Bx) <= 1.79e308);
     const double Tl = xok ? s.Tl : __builtin_nan(""), a = s.a;
@@ -963,6 +957,21 @@ __device__ __forceinline__ void prep_record_lanes(const double* __restrict__ th,
     }
 }
 
+// Sampler form of walker_kernel (vp_stretch_run): the workgroup of walker k of the active half forms ITS OWN
+// stretch-move proposal from the ensemble in HBM, evaluates it, and accepts or rejects it -- the whole half-step of
+// the ensemble is this one launch (csrc/sampler_kernels.h has the same arithmetic as separate kernels).
+struct StretchArgs {
+    double* pos;           // (W, D) ensemble; rows of the active half are updated in place
+    double* lp;            // (W)
+    long long* nacc;       // (W) accepted proposals
+    int* nanflag;
+    double* chain_pos;     // (W, D) row of the chain for this step, or NULL
+    double* chain_lp;      // (W)
+    double a;              // stretch scale
+    uint64_t seed, step;
+    int s0, c0, nC, half;  // active rows [s0, s0 + gridDim.x), complementary rows [c0, c0 + nC)
+};
+
 struct WalkerArgs {
     const double* theta;   // (W, D)
     const double* lb;      // (D) box prior (vfit_mcmc.py:291-295)
@@ -990,13 +999,13 @@ struct WalkerArgs {
 //      tile order -- no ticket, no atomics, no finalize launch.
 // Used for single-instrument contexts whose prior box keeps every line in the fast domain, for batches
 // small enough that launch overheads matter (capi.hip: enqueue_lnprob).
-template <int METHOD, bool CLUSTERS>   // CLUSTERS: the instrument has multipole cluster records (their preparation needs
-                                       // more registers than the tile work and spills to scratch; kept out of the
-                                       // plain instance)
+template <int METHOD, bool CLUSTERS, bool SAMPLER>   // CLUSTERS: the instrument has multipole cluster records (their
+                                       // preparation needs more registers than the tile work and spills to scratch;
+                                       // kept out of the plain instance).  SAMPLER: stretch-move half-step (StretchArgs)
 #ifndef VP_WALKER_WPE
 #define VP_WALKER_WPE 6
 #endif
-__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A) {
+__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A, StretchArgs S) {
     extern __shared__ double smem[];
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler knows it: the tile
@@ -1005,20 +1014,34 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
     double* __restrict__ red = smem + (size_t)nw * A.wave_lds;      // nw tile sums, then the prior flag
     const int nrec = T.L + T.NCm;
     double* __restrict__ lcw = A.lc + (size_t)w * nrec * LC_STRIDE;
-    const double* __restrict__ th = A.theta + (size_t)w * A.D;
+    // the theta row of this walker across the lanes of EVERY wave (D <= 64): read from the batch, or -- sampler
+    // form -- formed here: z ~ g(z) on [1/a, a], partner j from the complementary half, Y = X_j - (X_j - X_k) z
+    // (stretch_propose's arithmetic; every wave repeats the few instructions instead of waiting for one)
+    double thv;
+    if (SAMPLER) {
+        const Philox4 r = draw(S.seed, S.step, S.half, S.s0 + w, 0u);
+        const double t = (S.a - 1.0) * u01(r.v[0], r.v[1]) + 1.0;
+        const double z = t * t / S.a;
+        int j = (int)(u01(r.v[2], r.v[3]) * (double)S.nC);
+        j = j < S.nC - 1 ? j : S.nC - 1;
+        const int d = min(lane, A.D - 1);
+        const double x = S.pos[(size_t)(S.s0 + w) * A.D + d], c = S.pos[(size_t)(S.c0 + j) * A.D + d];
+        thv = c - (c - x) * z;
+    } else {
+        thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
+    }
     const int ngrp = (T.L + 3) >> 2, ncl = CLUSTERS ? ((T.NCm + 63) >> 6) : 0;
     const int ntask = 1 + ngrp + ncl;              // task 0: box prior; then line groups; then cluster records
     for (int task = wid; task < ntask; task += nw) {
         if (task == 0) {
-            int oob = 0;
-            for (int d = lane; d < A.D; d += 64) oob |= (th[d] < A.lb[d]) || (th[d] > A.ub[d]);
-            const bool any = __ballot(oob != 0) != 0ull;
+            const bool oob = lane < A.D && ((thv < A.lb[min(lane, A.D - 1)]) || (thv > A.ub[min(lane, A.D - 1)]));
+            const bool any = __ballot(oob) != 0ull;
             if (lane == 0) red[nw] = any ? 1.0 : 0.0;
         } else if (task <= ngrp) {
-            prep_record_lanes(th, A.D, T, (task - 1) * 4, lcw, lane);
+            prep_record_lanes(thv, T, (task - 1) * 4, lcw, lane);
         } else if (CLUSTERS) {
             const int k = (task - 1 - ngrp) * 64 + lane;
-            if (k < T.NCm) prep_cluster(th, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
+            if (k < T.NCm) prep_cluster(A.theta + (size_t)w * A.D, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
         }
     }
     const int p0 = wid * I.TP, nout = min(p0 + I.TP, I.P) - p0;
@@ -1031,23 +1054,60 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (red[nw] != 0.0) {                          // out-of-bounds walker: the model is not evaluated
+    const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
+    if (oobw && !SAMPLER) {
         if (tid == 0) A.lnprob[w] = -__builtin_inf();
         return;
     }
-    // the record pointer is re-made behind the barrier through an opaque scalar move, so no record load
-    // can be scheduled above it
-    unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
-    asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-    const double wsum = wave_sum(tile_work<METHOD, 0, false, true>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0));
-    if (lane == 0) red[wid] = wsum;
-    __syncthreads();
-    if (tid == 0) {
+    double total = 0.0;
+    if (!oobw) {
+        // the record pointer is re-made behind the barrier through an opaque scalar move, so no record load
+        // can be scheduled above it
+        unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
+        asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
+        const double wsum = wave_sum(tile_work<METHOD, 0, false, true>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0));
+        if (lane == 0) red[wid] = wsum;
+        __syncthreads();
+        if (wid != 0) return;
         double sk = 0.0;
         for (int k = 0; k < nw; ++k) sk += red[k];
-        double total = 0.0;
         total += -0.5 * (sk - A.sum_logw);         // vfit_mcmc.py:309-311
-        A.lnprob[w] = 0.0 + total;                 // lp + lnlike (vfit_mcmc.py:353)
+    } else if (wid != 0) {
+        return;
+    }
+    const double lnp = oobw ? -__builtin_inf() : 0.0 + total;      // lp + lnlike (vfit_mcmc.py:353)
+    if (!SAMPLER) {
+        if (lane == 0) A.lnprob[w] = lnp;
+        return;
+    }
+    // ---- sampler form: accept / reject by wave 0 (stretch_accept's arithmetic), the walker's chain entry --------
+    {
+        const int ws = S.s0 + w;
+        const Philox4 r = draw(S.seed, S.step, S.half, ws, 0u);     // the proposal again (cheaper than keeping it live)
+        const double t = (S.a - 1.0) * u01(r.v[0], r.v[1]) + 1.0;
+        const double z = t * t / S.a;
+        int j = (int)(u01(r.v[2], r.v[3]) * (double)S.nC);
+        j = j < S.nC - 1 ? j : S.nC - 1;
+        const int d = min(lane, A.D - 1);
+        const double x = S.pos[(size_t)ws * A.D + d], c = S.pos[(size_t)(S.c0 + j) * A.D + d];
+        const double y = c - (c - x) * z;
+        const double lp_old = S.lp[ws];
+        bool accept = false;
+        if (lnp != lnp) {
+            if (lane == 0) atomicExch(S.nanflag, 1);
+        } else {
+            const Philox4 r1 = draw(S.seed, S.step, S.half, ws, 1u);
+            const double lnq = (double)(A.D - 1) * log(z) + lnp - lp_old;
+            accept = log(u01(r1.v[0], r1.v[1])) < lnq;
+        }
+        if (accept) {
+            if (lane < A.D) S.pos[(size_t)ws * A.D + lane] = y;
+            if (lane == 0) { S.lp[ws] = lnp; S.nacc[ws] += 1; }
+        }
+        if (S.chain_pos) {
+            if (lane < A.D) S.chain_pos[(size_t)ws * A.D + lane] = accept ? y : x;
+            if (lane == 0) S.chain_lp[ws] = accept ? lnp : lp_old;
+        }
     }
 }
 

@@ -221,13 +221,18 @@ def _replay_stretch(lnprob, p0, nsteps, a, seed, step0=0):
     return pos, lp, chain, clp, nacc
 
 
-@pytest.mark.parametrize("W,nsteps", [(48, 40), (1100, 6)])      # fused accept+propose launch (W <= 1024) / separate launches
-def test_device_sampler_equals_an_independent_host_replay(W, nsteps):
+# launch structures of a half-step: accept+propose kernel + lnprob launches (W <= 1024), separate accept / propose
+# launches (W > 1024), and the WHOLE half-step in one walker_kernel launch (proposal, lnprob and accept inside each
+# walker's workgroup; automatic for half-ensembles of ~100-256 and ~410-512 walkers, forced here)
+@pytest.mark.parametrize("W,nsteps,one_launch", [(48, 40, False), (1100, 6, False), (48, 40, True), (512, 4, None)])
+def test_device_sampler_equals_an_independent_host_replay(W, nsteps, one_launch):
     """N1 pinned independently of the sampler kernels: same Philox draws, proposals and accept/reject restated in
     NumPy, lnprob of each half-ensemble proposal block from Engine.lnprob -- chain, stored lnprob, acceptance
     counts and final state must be bit-identical, also across a split run (step0)."""
     wl = _workload(W=W)
     eng, p0 = wl.engine, wl.thetas
+    if one_launch is not None:
+        eng.set_option("walker", 1 if one_launch else 0)
     seed = 0x1234_5678_9ABC_DEF1
     dev = eng.stretch_run(p0, nsteps, seed=seed, a=2.0)
     ref = _replay_stretch(eng.lnprob, p0, nsteps, 2.0, seed)
