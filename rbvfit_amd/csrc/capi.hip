@@ -561,6 +561,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     int *d_n, *d_b, *d_v;
 #define UP(T, h, n, d) if ((rc = upload<T>(c, &in, h, n, &d))) { for (void* p : in.allocs) hipFree(p); return rc; }
     UP(double, wave, P, d_wave) UP(double, ginv.data(), P, d_ginv) UP(double, flux, P, d_flux) UP(double, inv_sigma2, P, d_w)
+    kflip.resize((kflip.size() + 7) & ~(size_t)7, 0.0);       // zero-padded to whole groups of 8 (what the LSF loop reads)
     UP(double, kflip.data(), kflip.size(), d_k)
     UP(double, lambda0, L, d_l0) UP(double, freq0.data(), L, d_fr0) UP(double, gamma, L, d_g) UP(double, f, L, d_f) UP(double, zfac, L, d_z)
     UP(int, N_idx, L, d_n) UP(int, b_idx, L, d_b) UP(int, v_idx, L, d_v)
@@ -612,7 +613,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
             in.dev_s.ntiles = (P + in.dev_s.TP - 1) / in.dev_s.TP;
         }
     }
-    in.lds_bytes = (size_t)(span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + ((Kuse + 7) & ~7) + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
+    in.lds_bytes = (size_t)(span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
     if (in.lds_bytes + (size_t)std::max(0l, c->tune.lds_pad) > c->lds_limit) {
         for (void* p : in.allocs) hipFree(p);
         return fail(c, VP_EINVAL, "vp_add_instrument: a " + std::to_string(Kuse) + "-tap LSF with " + std::to_string(L) +

@@ -518,13 +518,12 @@ __device__ __forceinline__ void tile_sync() {
 // What a tile's threads fetch before they need the line records (LSF tap, exp table entry, the first
 // pass's pixel data): issued first, so that a wave's start-up is one memory round trip instead of
 // four -- and, in walker_kernel, runs under the record preparation.
-struct TilePre { double tap, e2, g[RB], wv[RB]; };
+struct TilePre { double e2, g[RB], wv[RB]; };
 __device__ __forceinline__ TilePre tile_preload(const InstDev& I, int p0, int nout, int tid) {
     const int lane = tid & 63, wid = tid >> 6;
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
     TilePre pre;
-    pre.tap = I.kflip[min(tid, I.K - 1)];
     pre.e2 = g_exp2_64[tid & 63];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -536,14 +535,68 @@ __device__ __forceinline__ TilePre tile_preload(const InstDev& I, int p0, int no
     return pre;
 }
 
+// LSF + chi^2 (or flux output) for one block of 2 * CGN * nthreads output pixels starting at `ob`: each lane produces
+// CGN pairs of adjacent pixels from sliding windows of the flux held in registers.
+template <int CGN, int OUT>
+__device__ __forceinline__ void lsf_block(const InstDev& I, const double* __restrict__ fl, int kn, int ob, int nout, int p0, int w,
+                                          int tid, int nthreads, double* __restrict__ out, int out_stride, double& acc) {
+    int o0[CGN];
+    const double2* __restrict__ fw[CGN];
+    double m0[CGN], m1[CGN];
+#pragma unroll
+    for (int c = 0; c < CGN; ++c) {
+        o0[c] = ob + c * 2 * nthreads + 2 * tid;              // even
+        const int oc = min(o0[c], (nout - 1) & ~1);           // lanes past the end re-read the last pair
+        fw[c] = reinterpret_cast<const double2*>(fl + oc);
+        m0[c] = 0.0; m1[c] = 0.0;
+    }
+    for (int j = 0; j < kn; j += 8) {
+        rec_t kb = as_rec(I.kflip) + j;                       // uniform address: scalar loads, SGPR operands of the FMAs
+        double f[CGN][10];
+#pragma unroll
+        for (int c = 0; c < CGN; ++c) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const double2 v = fw[c][(j >> 1) + q];
+                f[c][2 * q] = v.x; f[c][2 * q + 1] = v.y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double kj = kb[u];
+#pragma unroll
+            for (int c = 0; c < CGN; ++c) {
+                m0[c] = __builtin_fma(kj, f[c][u], m0[c]);
+                m1[c] = __builtin_fma(kj, f[c][u + 1], m1[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CGN; ++c) {
+        const int p = p0 + o0[c];
+        if (OUT == 0) {
+            if (o0[c] < nout) {
+                const double d = I.flux[p] - m0[c];
+                acc = __builtin_fma(d * d, I.w[p], acc);      // (flux-model)^2 * inv_sigma2
+            }
+            if (o0[c] + 1 < nout) {
+                const double d = I.flux[p + 1] - m1[c];
+                acc = __builtin_fma(d * d, I.w[p + 1], acc);
+            }
+        } else {
+            if (o0[c] < nout) out[(size_t)w * out_stride + p] = m0[c];
+            if (o0[c] + 1 < nout) out[(size_t)w * out_stride + p + 1] = m1[c];
+        }
+    }
+}
+
 // One tile of one walker -- output pixels [p0, p0 + nout) -- : tau -> exp -> LSF -> chi^2 (OUT = 0; returns this
 // LANE's sum of chi^2 terms) or model flux written to `out` (OUT = 1 convolved, 2 unconvolved).  `first` (uniform):
 // the LDS tables (taps, exp table) are staged; a wave that works through several tiles in a row passes false from
 // its second tile on.  PRE: the tables' entries and the first pass's pixels come from `pre` (tile_preload, issued
 // before the records were needed); without it they are loaded here.
 // `nthreads` threads (tid = 0..nthreads-1, whole waves) share the LDS block `fl`:
-//   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | LSF taps (zero-padded to 8k) | exp table |
-//   per-chunk "line core" masks
+//   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | exp table | per-chunk "line core" masks
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
 // fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
 template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true>
@@ -555,17 +608,12 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     const int lane = SOLO ? tid : (tid & 63), wid = SOLO ? 0 : (tid >> 6);     // SOLO: tid IS the lane
     const int TILE_THREADS = SOLO ? 64 : nthreads, nwaves = SOLO ? 1 : (nthreads >> 6);
     double* __restrict__ daw = fl + I.span + FL_PAD + 4;   // Dawson table for the line cores (16-B aligned)
-    double* __restrict__ ktap = daw + DAW_LDS_DOUBLES; // LSF taps, read back as LDS broadcasts
-    const int Kp = (I.K + 7) & ~7;                     // taps padded with zeros to whole groups of 8
-    double* __restrict__ etab = ktap + Kp;             // 2^(j/64) for the table-driven exp
+    const int Kp = (I.K + 7) & ~7;                     // taps are zero-padded to whole groups of 8 (in HBM, host side)
+    double* __restrict__ etab = daw + DAW_LDS_DOUBLES; // 2^(j/64) for the table-driven exp
     unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(etab + EXP_LDS_DOUBLES);
     const int nwords = (I.L + 63) >> 6;                // 64 lines per mask word
     const int nchunks = (n_eval + 63) >> 6;
-    if (first) {
-        if (tid < Kp) ktap[tid] = tid < I.K ? (PRE ? pre.tap : I.kflip[tid]) : 0.0;
-        for (int j = tid + TILE_THREADS; j < Kp; j += TILE_THREADS) ktap[j] = j < I.K ? I.kflip[j] : 0.0;
-        if (tid < EXP_LDS_DOUBLES) etab[tid] = PRE ? pre.e2 : g_exp2_64[tid];
-    }
+    if (first && tid < EXP_LDS_DOUBLES) etab[tid] = PRE ? pre.e2 : g_exp2_64[tid];
     if (tid < FL_PAD) fl[n_eval + tid] = 0.0;   // what the zero taps multiply must be finite
 
     // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
@@ -767,64 +815,21 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     //      Each lane produces TWO adjacent output pixels from a sliding window of the flux held in
     //      registers: per group of 8 taps it reads 10 consecutive doubles as five 16-byte LDS reads
     //      (lane stride 16 B: conflict-free) for 16 FMAs -- 5 B of LDS traffic per output and tap
-    //      instead of 8 B with one output per lane.  Taps are LDS broadcasts, zero-padded to groups of
-    //      8; the flux is followed by FL_PAD zeros (the window reads at most 9 doubles past the last
-    //      one).  Per output the taps are still accumulated in ascending order, so the result is
+    //      instead of 8 B with one output per lane.  Taps come by scalar loads (SGPR operands of the
+    //      FMAs; as LDS broadcasts they were 29 % of the phase's LDS cycles: C3 with its 101 taps +12 %,
+    //      C1 +1.5-2 %), zero-padded to groups of 8; the flux is followed by FL_PAD zeros (the window
+    //      reads at most 9 doubles past the last one).  Per output the taps are still accumulated in ascending order, so the result is
     //      bit-identical to the plain loop.
     double acc = 0.0;
     if (OUT != 2) {
-        const int kn = Kp;
-        constexpr int CG = 2;                                         // pixel pairs per lane and iteration (ILP)
-        for (int ob = 0; ob < nout; ob += 2 * CG * TILE_THREADS) {
-            int o0[CG];
-            const double2* __restrict__ fw[CG];
-            double m0[CG], m1[CG];
-#pragma unroll
-            for (int c = 0; c < CG; ++c) {
-                o0[c] = ob + c * 2 * TILE_THREADS + 2 * tid;          // even
-                const int oc = min(o0[c], (nout - 1) & ~1);           // lanes past the end re-read the last pair
-                fw[c] = reinterpret_cast<const double2*>(fl + oc);
-                m0[c] = 0.0; m1[c] = 0.0;
-            }
-            for (int j = 0; j < kn; j += 8) {
-                const double* __restrict__ kb = ktap + j;             // uniform address: LDS broadcasts
-                double f[CG][10];
-#pragma unroll
-                for (int c = 0; c < CG; ++c) {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        const double2 v = fw[c][(j >> 1) + q];
-                        f[c][2 * q] = v.x; f[c][2 * q + 1] = v.y;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double kj = kb[u];
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) {
-                        m0[c] = __builtin_fma(kj, f[c][u], m0[c]);
-                        m1[c] = __builtin_fma(kj, f[c][u + 1], m1[c]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CG; ++c) {
-                const int p = p0 + o0[c];
-                if (OUT == 0) {
-                    if (o0[c] < nout) {
-                        const double d = I.flux[p] - m0[c];
-                        acc = __builtin_fma(d * d, I.w[p], acc);      // (flux-model)^2 * inv_sigma2
-                    }
-                    if (o0[c] + 1 < nout) {
-                        const double d = I.flux[p + 1] - m1[c];
-                        acc = __builtin_fma(d * d, I.w[p + 1], acc);
-                    }
-                } else {
-                    if (o0[c] < nout) out[(size_t)w * out_stride + p] = m0[c];
-                    if (o0[c] + 1 < nout) out[(size_t)w * out_stride + p + 1] = m1[c];
-                }
-            }
-        }
+        // blocks of 4 output pixels per lane (two pairs: ILP) while more than 2 per lane remain, then blocks of 2: the
+        // tail of a 362-pixel tile is one 128-pixel block instead of a mostly masked 256-pixel one.  Same pixels per
+        // lane and same order of additions as one block size throughout: results do not change.
+        int ob = 0;
+        for (; nout - ob > 2 * TILE_THREADS; ob += 4 * TILE_THREADS)
+            lsf_block<2, OUT>(I, fl, Kp, ob, nout, p0, w, tid, TILE_THREADS, out, out_stride, acc);
+        for (; ob < nout; ob += 2 * TILE_THREADS)
+            lsf_block<1, OUT>(I, fl, Kp, ob, nout, p0, w, tid, TILE_THREADS, out, out_stride, acc);
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }
@@ -1046,12 +1051,8 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
     }
     const int p0 = wid * I.TP, nout = min(p0 + I.TP, I.P) - p0;
     const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
-    {   // the wave's LDS tables (taps, exp table) are staged while it waits for the records anyway
-        double* __restrict__ ktap = fl + I.span + FL_PAD + 4 + DAW_LDS_DOUBLES;
-        const int Kp = (I.K + 7) & ~7;
-        for (int j = lane; j < Kp; j += 64) ktap[j] = j < I.K ? I.kflip[j] : 0.0;
-        ktap[Kp + lane] = g_exp2_64[lane];                     // etab = ktap + Kp, EXP_LDS_DOUBLES = 64 entries
-    }
+    fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = g_exp2_64[lane];   // the wave's exp table (EXP_LDS_DOUBLES = 64 entries),
+                                                                           // staged while it waits for the records anyway
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
