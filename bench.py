@@ -384,7 +384,7 @@ def rank_main(args):
         roof["valu_fp64"] = dict(bound="valu_fp64", unit="TFLOP/s", peak=FP64_VALU_PEAK_TFLOPS, achieved=vt,
                                  frac=vt / FP64_VALU_PEAK_TFLOPS, algorithmic_flops_per_eval=wl.algorithmic_flops_per_eval,
                                  model="per (line,pixel) 8 + (150 if |x|<8 else 12) + 1; per pixel 30 + 2K + 4")
-        host_rate = host_lat = sampler_steps = None
+        host_rate = host_lat = sampler_steps = slice_info = None
         if not args.no_extras:
             # measured device copy bandwidth next to the vendor peak (read + write of a 1 GiB buffer)
             src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
@@ -421,6 +421,16 @@ def rank_main(args):
                 ts0 = time.perf_counter()
                 wl.engine.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
                 sampler_steps = nst / (time.perf_counter() - ts0)
+                # and the reference's second sampler (zeus' ensemble slice sampling) with the walker loop on the GPU
+                if W <= 2048:
+                    nsl = 60 if args.config in ("C0", "C1") else 6
+                    r0 = wl.engine.slice_run(wl.thetas, max(2, nsl // 6), seed=1, store_chain=False)
+                    ts0 = time.perf_counter()
+                    r1 = wl.engine.slice_run(r0["pos"], nsl, lnprob=r0["lnprob"], seed=1, step0=max(2, nsl // 6), mu=r0["mu"],
+                                             tune=r0["tune"], store_chain=False)
+                    dts = time.perf_counter() - ts0
+                    slice_info = dict(steps_per_sec=nsl / dts, lnprob_evals_per_walker_step=r1["n_evals"] / (nsl * W),
+                                      evals_per_sec=r1["n_evals"] / dts, mu=r1["mu"])
 
     result = d_out.cpu().numpy()
     if rank == 0:
@@ -441,6 +451,9 @@ def rank_main(args):
             "mcmc_steps_per_sec": sampler_steps,
             "mcmc_steps_per_sec_note": "device-resident stretch move (vp_stretch_run): one ensemble step = two half-ensemble "
                                        "lnprob passes + propose/accept kernels; rank 0's walkers",
+            "slice_sampler": slice_info,
+            "slice_sampler_note": "device-resident ensemble slice sampling (vp_slice_run, zeus' differential move): ensemble steps/s, "
+                                  "lnprob evaluations per walker and step, and the evaluations/s they amount to",
             "host_entry_evals_per_sec_pcie_inclusive": host_rate,
             "host_entry_latency": host_lat,
             "roofline": roof,
