@@ -37,6 +37,7 @@ struct Tuning {
     int waves = 0;              // waves per tile workgroup, 0 = default (read when an instrument is added)
     long lds_pad = 0;           // extra LDS bytes per tile workgroup: occupancy experiments
     int no_fused_accept = 0;    // device sampler: separate accept / propose launches
+    int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
 
 struct Knob { const char* name; const char* env; int is_long; size_t off; };
@@ -47,7 +48,7 @@ const Knob g_knobs[] = {
     VP_KNOB(zerocopy_max, "RBVFIT_AMD_ZEROCOPY_MAX", 1),
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
-    VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0),
+    VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -907,41 +908,43 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
     if ((chain == nullptr) != (chain_lnprob == nullptr)) return fail(c, VP_EINVAL, "vp_slice_run: chain and chain_lnprob go together");
     HIP_TRY(c, hipSetDevice(c->device));
     const int half = W / 2;
-    if ((rc = ensure_workspace(c, W))) return rc;
+    const int B = std::max(2, std::min(vp::SLICE_MAXC, c->tune.slice_rows)) * half;   // rows of every round's lnprob batch
+    if ((rc = ensure_workspace(c, std::max(W, B)))) return rc;
     hipStream_t s = c->stream;
-    // device state (doubles first): pos (W,D) | lp (W) | trial (half,D) | lnp_rows (half) | X0, eta (half,D each) |
-    // Z0, L, R, Wd (half each) | mu[3] | mu_hist (nsteps) | chain chunk; then the integer state
+    // device state (doubles first): pos (W,D) | lp (W) | trial (B,D) | lnp_rows (B) | X0, eta (half,D each) |
+    // Z0, L, R (half each) | T (half, MAXC) | mu[3] | mu_hist (nsteps) | chain chunk; then the integer state
     const size_t row = (size_t)W * (D + 1);
     size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
-    const size_t nd = (size_t)W * D + W + (size_t)half * D + half + 2 * (size_t)half * D + 4 * (size_t)half + 4 + (size_t)std::max(nsteps, 1);
-    const size_t ni = (size_t)W + 6 * (size_t)half + 16;                       // perm | J K phase nshr row widx | n_active, nan
+    const size_t nd = (size_t)W * D + W + (size_t)B * D + B + 2 * (size_t)half * D + (3 + vp::SLICE_MAXC) * (size_t)half + 4 +
+                      (size_t)std::max(nsteps, 1);
+    const size_t ni = (size_t)W + 7 * (size_t)half + 16;                       // perm | J K phase sides nshr row widx | n_active, nan, ncand
     const size_t bytes = (nd + chunk * row) * sizeof(double) + 4 * sizeof(long long) + ni * sizeof(int) + 64;
     if ((rc = ensure_scratch(c, bytes))) return rc;
     double* d_pos = c->d_scratch;
     double* d_lp = d_pos + (size_t)W * D;
     double* d_trial = d_lp + W;
-    double* d_rows = d_trial + (size_t)half * D;
+    double* d_rows = d_trial + (size_t)B * D;
     vp::SliceState st{};
-    st.X0 = d_rows + half;
+    st.X0 = d_rows + B;
     st.eta = st.X0 + (size_t)half * D;
     st.Z0 = st.eta + (size_t)half * D;
-    st.L = st.Z0 + half; st.R = st.L + half; st.Wd = st.R + half;
-    double* d_mu = st.Wd + half;                                               // 4 doubles (3 used)
+    st.L = st.Z0 + half; st.R = st.L + half; st.T = st.R + half;
+    double* d_mu = st.T + (size_t)half * vp::SLICE_MAXC;                       // 4 doubles (3 used)
     double* d_muhist = d_mu + 4;
     double* d_chain = d_muhist + std::max(nsteps, 1);
     long long* d_ll = reinterpret_cast<long long*>(d_chain + chunk * row);     // n_evals, nexp, ncon, (pad)
     int* d_int = reinterpret_cast<int*>(d_ll + 4);
     int* d_perm = d_int;
-    st.J = d_perm + W; st.K = st.J + half; st.phase = st.K + half; st.nshr = st.phase + half; st.row = st.nshr + half;
-    st.widx = st.row + half;
+    st.J = d_perm + W; st.K = st.J + half; st.phase = st.K + half; st.sides = st.phase + half; st.nshr = st.sides + half;
+    st.row = st.nshr + half; st.widx = st.row + half;
     int* d_nact = st.widx + half;
     int* d_nan = d_nact + 1;
-    vp::SliceCounters cn{d_nact, d_ll, d_ll + 1, d_ll + 2, d_nan, d_mu};
+    vp::SliceCounters cn{d_nact, d_ll, d_ll + 1, d_ll + 2, d_nan, d_nact + 2, d_mu};
     const double h_mu[4] = {*mu, 0.0, *tune ? 1.0 : 0.0, 0.0};
     HIP_TRY(c, hipMemcpyAsync(d_pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_mu, h_mu, sizeof(h_mu), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync(d_ll, 0, 4 * sizeof(long long), s));
-    HIP_TRY(c, hipMemsetAsync(d_nact, 0, 2 * sizeof(int), s));
+    HIP_TRY(c, hipMemsetAsync(d_nact, 0, 4 * sizeof(int), s));
     if (have_lnprob) HIP_TRY(c, hipMemcpyAsync(d_lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, s));
     else if ((rc = enqueue_lnprob(c, W, d_pos, d_lp, s))) return rc;
     {   // the start state must be finite everywhere (zeus: "Invalid walker initial positions")
@@ -964,13 +967,13 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
                                tolerance, patience, (done + it) > 0 ? d_muhist + (done + it - 1) : (double*)nullptr);
             for (int h = 0; h < 2; ++h) {
                 hipLaunchKernelGGL(vp::slice_init_kernel, dim3(1), dim3(thr), 0, s, d_pos, d_lp, d_perm, half, D, h, seed, step,
-                                   gamma0, maxsteps, st, cn, d_trial);
+                                   gamma0, maxsteps, B, st, cn, d_trial);
                 int rounds = 0;
                 for (;;) {
                     for (int r = 0; r < group; ++r) {
-                        if ((rc = enqueue_lnprob(c, half, d_trial, d_rows, s))) return rc;
+                        if ((rc = enqueue_lnprob(c, B, d_trial, d_rows, s))) return rc;
                         hipLaunchKernelGGL(vp::slice_update_kernel, dim3(1), dim3(thr), 0, s, d_pos, d_lp, d_rows, half, D, h, seed,
-                                           step, st, cn, d_trial);
+                                           step, B, st, cn, d_trial);
                     }
                     rounds += group;
                     int h_state[2] = {0, 0};
@@ -981,7 +984,7 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
                     if (rounds > 4 * maxsteps + 4096) return fail(c, VP_ESTATE, "vp_slice_run: a slice did not terminate");
                     group = 2;                       // stragglers: look again after a couple of rounds
                 }
-                group = std::max(3, std::min(16, rounds));   // next half-step: about as many rounds as this one needed
+                group = std::max(2, std::min(16, rounds));   // next half-step: about as many rounds as this one needed
             }
             if (chain) {
                 HIP_TRY(c, hipMemcpyAsync(d_chain + (size_t)it * W * D, d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToDevice, s));

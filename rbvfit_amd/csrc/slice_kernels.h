@@ -8,15 +8,16 @@
 // Per iteration: a random split of the ensemble into two halves; each walker k of the active half
 // slices along eta_k = mu * 2.38/sqrt(2D) * (X_l - X_m), l != m drawn from the other half, with
 // height Z0 = lnprob(X_k) + ln u.  Every walker runs its own little state machine
-//     OUT_L (expand the left edge while lnprob(edge) > Z0 and budget J > 0)
-//  -> OUT_R (same on the right, budget K)
+//     OUT    (expand the left edge while lnprob(edge) > Z0 and budget J > 0; same on the right, budget K)
 //  -> SHRINK (draw inside [L, R]; accept when lnprob > Z0, else pull the bracket in)
 //  -> DONE
-// and ONE lnprob batch per round evaluates the pending trial point of every walker that is not
-// DONE, whatever its phase.  The batch always has `half` rows: the active walkers' trial points are
-// compacted to the front, the rest is filled with +inf, which the box prior turns into -inf without
-// evaluating the model (so the tile workgroups of filler rows exit at once and the tile geometry --
-// hence the last bit of every lnprob -- does not depend on how many walkers are still active).
+// (the two edges of OUT are independent and are worked on side by side) and ONE lnprob batch per round
+// evaluates the next trial points of every walker that is not DONE.  The batch always has W rows
+// (twice the half-ensemble): the active walkers are compacted to the front and share the rows evenly
+// -- 2 candidates each while all are active, up to 8 for the last stragglers (slice_emit) --, the rest
+// is filled with +inf, which the box prior turns into -inf without evaluating the model (so the tile
+// workgroups of filler rows exit at once and the tile geometry -- hence the last bit of every lnprob --
+// does not depend on how many walkers are still active).
 //
 // Randomness: Philox4x32-10 keyed by (seed; walker, step, half, purpose) like the stretch move, so a
 // run is reproducible, splittable into calls, and can be replayed on the host draw by draw
@@ -27,8 +28,9 @@
 
 namespace vp {
 
-constexpr int SL_OUT_L = 0, SL_OUT_R = 1, SL_SHRINK = 2, SL_DONE = 3;
+constexpr int SL_OUT = 0, SL_SHRINK = 2, SL_DONE = 3;
 constexpr int SLICE_MAX_HALF = 1024;    // one workgroup handles a half-ensemble (W <= 2048)
+constexpr int SLICE_MAXC = 8;           // candidates a walker may have in one round
 
 struct SliceState {          // per walker-slot k of the active half (device arrays of length half)
     double* X0;              // (half, D) position at the start of the half-step
@@ -36,21 +38,23 @@ struct SliceState {          // per walker-slot k of the active half (device arr
     double* Z0;              // slice height
     double* L;               // bracket
     double* R;
-    double* Wd;              // pending shrink draw
+    double* T;               // (half, SLICE_MAXC) slice parameters of the candidates of the current round
     int* J;                  // expansion budgets left / right
     int* K;
-    int* phase;
+    int* phase;              // SL_OUT | SL_SHRINK | SL_DONE
+    int* sides;              // SL_OUT: bit 0 = left edge settled, bit 1 = right edge settled
     int* nshr;               // shrink draws used so far
-    int* row;                // row of the pending trial point in the batch, -1 when none
+    int* row;                // rank of the walker among the active ones (its candidates are rows row*nc ... of the batch), -1 when DONE
     int* widx;               // walker index w = perm[h * half + k]
 };
 
 struct SliceCounters {       // device scalars
-    int* n_active;           // walkers with a pending trial point (after the last advance)
-    long long* n_evals;      // trial points evaluated so far
+    int* n_active;           // walkers that are not DONE (after the last update); [1] = nanflag, [2] = candidates per walker of the batch
+    long long* n_evals;      // trial points the sequential algorithm would have evaluated so far
     long long* nexp;         // expansions / contractions of the current iteration (mu tuning)
     long long* ncon;
     int* nanflag;
+    int* ncand;
     double* mu;              // [0] mu, [1] number of consecutive in-tolerance iterations, [2] tuning on (1.0) / off (0.0)
 };
 
@@ -72,46 +76,72 @@ __device__ inline int block_scan01(bool flag, int* lds_counts, int* total) {
     return base + within;
 }
 
-// Pending trial point X0 + t eta of slot k in its current phase (advancing through exhausted phases): sets t;
-// false when DONE.
-__device__ inline bool slice_trial(int k, const SliceState& st, uint64_t seed, uint64_t step, int h, double* tout) {
-    int ph = st.phase[k];
-    if (ph == SL_OUT_L && st.J[k] <= 0) ph = SL_OUT_R;
-    if (ph == SL_OUT_R && st.K[k] <= 0) ph = SL_SHRINK;
-    st.phase[k] = ph;
-    if (ph == SL_DONE) return false;
-    double t;
-    if (ph == SL_OUT_L) t = st.L[k];
-    else if (ph == SL_OUT_R) t = st.R[k];
-    else {
-        const Philox4 r = draw(seed, step, h, st.widx[k], 32u + (uint32_t)st.nshr[k]);
-        const double u = u01(r.v[0], r.v[1]);
-        t = st.L[k] + u * (st.R[k] - st.L[k]);
-        st.Wd[k] = t;
-    }
-    *tout = t;
-    return true;
-}
-
-// Writes the batch for the next round: active slots' trial points compacted to the front, +inf filler behind.
-__device__ inline void slice_emit(int k, int half, bool active, double t, const SliceState& st, int D,
-                                  double* __restrict__ trial, const SliceCounters& cn, int* lds_counts) {
-    if (k < half) {
-        double* row = trial + (size_t)k * D;
+// The next round's batch.  Every walker that is not DONE gets `nc` rows (nc even, 2 <= nc <= SLICE_MAXC, the more
+// the fewer walkers are left: nc = batch rows / active walkers) holding the NEXT nc trial points the sequential
+// procedure could ask for, in its order, under the assumption that each one before them comes out the way that keeps
+// the procedure going:
+//   SL_OUT     nc/2 per side: the left edge at L, L-1, ... (as long as the budget J lasts) and the right edge at
+//              R, R+1, ...: an edge expands while lnprob(edge) > Z0, so candidate s is only looked at if 0..s-1 expanded;
+//   SL_SHRINK  the shrink draws c, c+1, ...: Wd = L' + u (R' - L') with the bracket pulled in behind every earlier
+//              draw -- which side it is pulled in from depends on the sign of the draw alone, not on its lnprob, so the
+//              whole rejected-so-far sequence is known in advance; the first draw with lnprob > Z0 is accepted.
+// The update kernel consumes the results in order and stops at the first one that ends the phase, so the accepted
+// point, the brackets, the expansion / contraction counts (hence mu) and the count of evaluations are exactly those
+// of the one-evaluation-at-a-time procedure; speculation only buys rounds (latency) with throughput.
+// Rows of invalid candidates and of DONE walkers hold +inf, which the box prior rejects without evaluating the model.
+__device__ inline void slice_emit(int k, int half, const SliceState& st, int D, int batch_rows, uint64_t seed, uint64_t step,
+                                  int h, double* __restrict__ trial, const SliceCounters& cn, int* lds_counts) {
+    const bool active = k < half && st.phase[k] != SL_DONE;
+    for (int r = k; r < batch_rows; r += blockDim.x) {
+        double* row = trial + (size_t)r * D;
         for (int d = 0; d < D; ++d) row[d] = __builtin_inf();
     }
     int total;
-    const int r = block_scan01(active, lds_counts, &total);       // (contains barriers: the filler is complete behind it)
-    if (k < half) st.row[k] = active ? r : -1;
+    const int a = block_scan01(active, lds_counts, &total);       // (contains barriers: the filler is complete behind it)
+    int nc = total > 0 ? (batch_rows / total) & ~1 : 2;
+    nc = nc < 2 ? 2 : (nc > SLICE_MAXC ? SLICE_MAXC : nc);
+    if (k < half) st.row[k] = active ? a : -1;
     if (active) {
-        double* row = trial + (size_t)r * D;
+        double* T = st.T + (size_t)k * SLICE_MAXC;
+        bool valid[SLICE_MAXC];
+        if (st.phase[k] == SL_OUT) {
+            const int hs = nc >> 1, sd = st.sides[k], J = st.J[k], K = st.K[k];
+            const double L = st.L[k], R = st.R[k];
+#pragma unroll
+            for (int s = 0; s < SLICE_MAXC; ++s) {
+                const bool left = s < hs;
+                const int i = left ? s : s - hs;
+                T[s] = left ? L - (double)i : R + (double)i;
+                valid[s] = s < nc && (left ? (!(sd & 1) && J > i) : (!(sd & 2) && K > i));
+            }
+        } else {
+            double Lc = st.L[k], Rc = st.R[k];
+            const int c0 = st.nshr[k];
+#pragma unroll
+            for (int s = 0; s < SLICE_MAXC; ++s) {
+                valid[s] = s < nc;
+                if (s < nc) {
+                    const Philox4 r = draw(seed, step, h, st.widx[k], 32u + (uint32_t)(c0 + s));
+                    const double wd = Lc + u01(r.v[0], r.v[1]) * (Rc - Lc);
+                    T[s] = wd;
+                    if (wd < 0.0) Lc = wd; else Rc = wd;
+                }
+            }
+        }
         const double* x0 = st.X0 + (size_t)k * D;
         const double* e = st.eta + (size_t)k * D;
-        for (int d = 0; d < D; ++d) row[d] = x0[d] + t * e[d];
+#pragma unroll
+        for (int s = 0; s < SLICE_MAXC; ++s) {
+            if (s < nc && valid[s]) {
+                double* row = trial + ((size_t)a * nc + s) * D;
+                const double t = T[s];
+                for (int d = 0; d < D; ++d) row[d] = x0[d] + t * e[d];
+            }
+        }
     }
     if (threadIdx.x == 0) {
         *cn.n_active = total;
-        *cn.n_evals += total;
+        *cn.ncand = nc;
     }
 }
 
@@ -161,11 +191,10 @@ __global__ __launch_bounds__(1024) void slice_begin_kernel(int W, uint64_t seed,
 __global__ __launch_bounds__(1024) void slice_init_kernel(const double* __restrict__ pos, const double* __restrict__ lp,
                                                           const int* __restrict__ perm, int half, int D, int h,
                                                           uint64_t seed, uint64_t step, double gamma0, int maxsteps,
-                                                          SliceState st, SliceCounters cn, double* __restrict__ trial) {
+                                                          int batch_rows, SliceState st, SliceCounters cn,
+                                                          double* __restrict__ trial) {
     __shared__ int lds_counts[16];
     const int k = threadIdx.x;
-    double t = 0.0;
-    bool active = false;
     if (k < half) {
         const int* S = perm + h * half;
         const int* C = perm + (1 - h) * half;
@@ -191,62 +220,86 @@ __global__ __launch_bounds__(1024) void slice_init_kernel(const double* __restri
         st.R[k] = L + 1.0;
         int J = (int)((double)maxsteps * u01(rc.v[0], rc.v[1]));
         J = J < maxsteps - 1 ? J : maxsteps - 1;
+        const int K = (maxsteps - 1) - J;
         st.J[k] = J;
-        st.K[k] = (maxsteps - 1) - J;
-        st.phase[k] = SL_OUT_L;
+        st.K[k] = K;
+        const int sd = (J <= 0 ? 1 : 0) | (K <= 0 ? 2 : 0);
+        st.sides[k] = sd;
+        st.phase[k] = sd == 3 ? SL_SHRINK : SL_OUT;
         st.nshr[k] = 0;
-        active = slice_trial(k, st, seed, step, h, &t);
     }
-    slice_emit(k, half, active, t, st, D, trial, cn, lds_counts);
+    slice_emit(k, half, st, D, batch_rows, seed, step, h, trial, cn, lds_counts);
 }
 
-// After a round's lnprob batch: every slot with a pending trial point takes its result, moves its state machine
-// (an accepted shrink draw updates the walker's position and lnprob in place), and the next batch is written.
+// After a round's lnprob batch: every walker that is not DONE consumes the results of its candidates in order, up to
+// the first one that ends its phase (an accepted shrink draw updates the walker's position and lnprob in place),
+// then the next batch is written.
 __global__ __launch_bounds__(1024) void slice_update_kernel(double* __restrict__ pos, double* __restrict__ lp,
                                                             const double* __restrict__ lnp_rows, int half, int D, int h,
-                                                            uint64_t seed, uint64_t step, SliceState st, SliceCounters cn,
-                                                            double* __restrict__ trial) {
+                                                            uint64_t seed, uint64_t step, int batch_rows, SliceState st,
+                                                            SliceCounters cn, double* __restrict__ trial) {
     __shared__ int lds_counts[16];
-    __shared__ int s_exp, s_con;
+    __shared__ int s_exp, s_con, s_ev;
     const int k = threadIdx.x;
-    if (k == 0) { s_exp = 0; s_con = 0; }
+    if (k == 0) { s_exp = 0; s_con = 0; s_ev = 0; }
     __syncthreads();
-    double t = 0.0;
-    bool active = false;
+    const int nc = *cn.ncand;
     if (k < half && st.row[k] >= 0) {
-        const int r = st.row[k];
-        const double v = lnp_rows[r];
+        const double* res = lnp_rows + (size_t)st.row[k] * nc;
+        const double* T = st.T + (size_t)k * SLICE_MAXC;
         const double z0 = st.Z0[k];
-        const int ph = st.phase[k];
-        if (v != v) {
+        int nev = 0, nex = 0, nco = 0;
+        bool nan = false;
+        if (st.phase[k] == SL_OUT) {
+            const int hs = nc >> 1;
+            int sd = st.sides[k], J = st.J[k], K = st.K[k];
+            double L = st.L[k], R = st.R[k];
+            for (int s = 0; s < hs && !(sd & 1); ++s) {            // left edge: expands while lnprob(edge) > Z0 and budget lasts
+                const double v = res[s];
+                ++nev;
+                if (v != v) { nan = true; break; }
+                if (v > z0) { L -= 1.0; J -= 1; ++nex; if (J <= 0) sd |= 1; }
+                else sd |= 1;
+            }
+            for (int s = 0; s < hs && !(sd & 2) && !nan; ++s) {    // right edge
+                const double v = res[hs + s];
+                ++nev;
+                if (v != v) { nan = true; break; }
+                if (v > z0) { R += 1.0; K -= 1; ++nex; if (K <= 0) sd |= 2; }
+                else sd |= 2;
+            }
+            st.L[k] = L; st.R[k] = R; st.J[k] = J; st.K[k] = K; st.sides[k] = sd;
+            if (sd == 3) st.phase[k] = SL_SHRINK;
+        } else {
+            double L = st.L[k], R = st.R[k];
+            int c = st.nshr[k];
+            for (int s = 0; s < nc; ++s) {
+                const double v = res[s], wd = T[s];
+                ++nev;
+                if (v != v) { nan = true; break; }
+                if (v > z0) {                                      // accept: the trial point (re-formed: same bits) is the new position
+                    const int w = st.widx[k];
+                    const double* x0 = st.X0 + (size_t)k * D;
+                    const double* e = st.eta + (size_t)k * D;
+                    for (int d = 0; d < D; ++d) pos[(size_t)w * D + d] = x0[d] + wd * e[d];
+                    lp[w] = v;
+                    st.phase[k] = SL_DONE;
+                    break;
+                }
+                if (wd < 0.0) L = wd; else R = wd;
+                ++c; ++nco;
+            }
+            st.L[k] = L; st.R[k] = R; st.nshr[k] = c;
+        }
+        if (nan) {
             atomicExch(cn.nanflag, 1);
             st.phase[k] = SL_DONE;
-        } else if (ph == SL_OUT_L) {
-            if (v > z0) { st.L[k] -= 1.0; st.J[k] -= 1; atomicAdd(&s_exp, 1); }
-            else st.phase[k] = SL_OUT_R;
-        } else if (ph == SL_OUT_R) {
-            if (v > z0) { st.R[k] += 1.0; st.K[k] -= 1; atomicAdd(&s_exp, 1); }
-            else st.phase[k] = SL_SHRINK;
-        } else {
-            if (v > z0) {                                          // accept: the trial point (re-formed: same bits) is the new position
-                const int w = st.widx[k];
-                const double wd = st.Wd[k];
-                const double* x0 = st.X0 + (size_t)k * D;
-                const double* e = st.eta + (size_t)k * D;
-                for (int d = 0; d < D; ++d) pos[(size_t)w * D + d] = x0[d] + wd * e[d];
-                lp[w] = v;
-                st.phase[k] = SL_DONE;
-            } else {
-                const double wd = st.Wd[k];
-                if (wd < 0.0) st.L[k] = wd; else st.R[k] = wd;
-                st.nshr[k] += 1;
-                atomicAdd(&s_con, 1);
-            }
         }
-        active = slice_trial(k, st, seed, step, h, &t);
+        atomicAdd(&s_ev, nev); atomicAdd(&s_exp, nex); atomicAdd(&s_con, nco);
     }
-    slice_emit(k, half, active, t, st, D, trial, cn, lds_counts);
-    if (k == 0) { *cn.nexp += s_exp; *cn.ncon += s_con; }
+    __syncthreads();
+    if (k == 0) { *cn.nexp += s_exp; *cn.ncon += s_con; *cn.n_evals += s_ev; }
+    slice_emit(k, half, st, D, batch_rows, seed, step, h, trial, cn, lds_counts);
 }
 
 }  // namespace vp

@@ -258,10 +258,11 @@ def test_initial_nan_lnprob_is_an_error():
 
 # ---- independent host replay of vp_slice_run (csrc/slice_kernels.h) ----------------------------------------
 def _replay_slice(lnprob, p0, nsteps, seed, mu=1.0, tune=True, tolerance=0.05, patience=5, maxsteps=10000, step0=0):
-    """zeus' ensemble slice sampling (the reference's sampler='zeus', vfit_mcmc.py:425-440) as vp_slice_run performs
-    it, restated in NumPy with the same Philox draws: random split by ranking 64-bit keys, differential move,
-    per-walker state machine OUT_L -> OUT_R -> SHRINK -> DONE, one lnprob batch per round over the walkers that are
-    not DONE (active trial points first, then +inf filler rows to the fixed batch size W/2)."""
+    """zeus' ensemble slice sampling (the reference's sampler='zeus', vfit_mcmc.py:425-440) restated in NumPy with
+    the Philox draws of vp_slice_run: random split by ranking 64-bit keys, differential move, per-walker state
+    machine OUT_L -> OUT_R -> SHRINK -> DONE, ONE trial point per walker and round.  The device evaluates several
+    candidate points per walker and round (both edges at once, shrink draws ahead of their turn) and must end up with
+    exactly what this one-at-a-time procedure produces, its count of evaluations included."""
     pos = np.array(p0, dtype=np.float64)
     W, D = pos.shape
     half = W // 2
