@@ -295,45 +295,89 @@ __device__ __forceinline__ void dawson_to_lds(double* __restrict__ daw, int tid,
         daw[idx] = v;
     }
 }
-__device__ __forceinline__ double core_taylor_H_lds(double x, double a, double ea2, int nodd,
-                                                    const double* __restrict__ daw,
-                                                    const double* __restrict__ et) {
-    const double ax = fabs(x);
-    const int i = min((int)(ax * 2.0), DAW_NI - 1);
-    const double t = __builtin_fma(ax, 4.0, -(double)(2 * i + 1));
-    const double* __restrict__ cF = daw + i * (DAW_DEG + 1);
-    double F = cF[DAW_DEG];
+// N independent pixels per lane for ONE line (a, ea2, nodd wave-uniform): the stages of the N evaluations sit side
+// by side in one basic block, so that a wave that is alone on its SIMD overlaps their dependent chains.  Every
+// pixel sees exactly the operations of the N = 1 form.
+template <int N>
+__device__ __forceinline__ void core_taylor_H_lds_n(const double (&x)[N], double a, double ea2, int nodd,
+                                                    const double* __restrict__ daw, const double* __restrict__ et,
+                                                    double (&H)[N]) {
+    double ax[N], t[N], F[N], G[N];
+    int i[N];
+    bool hi = false;
 #pragma unroll
-    for (int k = DAW_DEG - 1; k >= 0; --k) F = __builtin_fma(F, t, cF[k]);
-    double G = __builtin_fma(-2.0 * ax, F, 1.0);
-    if (__ballot(i >= DAW_GLO) != 0ull) {             // some lane beyond |x| = 5: G from its own polynomial there
-        const double* __restrict__ cG = daw + DAW_F_DOUBLES + max(i - DAW_GLO, 0) * (DAW_DEG + 1);
-        double Gt = cG[DAW_DEG];
+    for (int r = 0; r < N; ++r) {
+        ax[r] = fabs(x[r]);
+        i[r] = min((int)(ax[r] * 2.0), DAW_NI - 1);
+        t[r] = __builtin_fma(ax[r], 4.0, -(double)(2 * i[r] + 1));
+        hi = hi || (i[r] >= DAW_GLO);
+    }
+    {
+        const double* __restrict__ cF[N];
 #pragma unroll
-        for (int k = DAW_DEG - 1; k >= 0; --k) Gt = __builtin_fma(Gt, t, cG[k]);
-        G = (i >= DAW_GLO) ? Gt : G;
+        for (int r = 0; r < N; ++r) { cF[r] = daw + i[r] * (DAW_DEG + 1); F[r] = cF[r][DAW_DEG]; }
+#pragma unroll
+        for (int k = DAW_DEG - 1; k >= 0; --k) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) F[r] = __builtin_fma(F[r], t[r], cF[r][k]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) G[r] = __builtin_fma(-2.0 * ax[r], F[r], 1.0);
+    if (__ballot(hi) != 0ull) {                       // some lane beyond |x| = 5: G from its own polynomial there
+        const double* __restrict__ cG[N];
+        double Gt[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) { cG[r] = daw + DAW_F_DOUBLES + max(i[r] - DAW_GLO, 0) * (DAW_DEG + 1); Gt[r] = cG[r][DAW_DEG]; }
+#pragma unroll
+        for (int k = DAW_DEG - 1; k >= 0; --k) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) Gt[r] = __builtin_fma(Gt[r], t[r], cG[r][k]);
+        }
+#pragma unroll
+        for (int r = 0; r < N; ++r) G[r] = (i[r] >= DAW_GLO) ? Gt[r] : G[r];
     }
     const double c = 1.1283791670955125739;          // 2/sqrt(pi)
-    double vp = c * F, vc = c * G;                    // v_0, v_1
-    const double E = exp_neg_tab(ax * ax, et);
+    double vp[N], vc[N], E[N], acc[N];
     const double a2 = a * a;
     double apow = -a;
-    double acc = apow * vc;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        vp[r] = c * F[r]; vc[r] = c * G[r];           // v_0, v_1
+        E[r] = exp_neg_tab(ax[r] * ax[r], et);
+        acc[r] = apow * vc[r];
+    }
     constexpr double R[12] = {-1.0, -2.0 / 3, -0.5, -0.4, -2.0 / 6, -2.0 / 7, -0.25, -2.0 / 9, -0.2, -2.0 / 11,
                               -2.0 / 12, -2.0 / 13};
 #pragma unroll
     for (int k = 1; k < 7; ++k) {
         if (k < nodd) {                               // wave-uniform
-            const double v1 = R[2 * k - 2] * __builtin_fma(ax, vc, vp);
-            const double v2 = R[2 * k - 1] * __builtin_fma(ax, v1, vc);
-            vp = v1; vc = v2;
             apow = -apow * a2;
-            acc = __builtin_fma(apow, vc, acc);
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                const double v1 = R[2 * k - 2] * __builtin_fma(ax[r], vc[r], vp[r]);
+                const double v2 = R[2 * k - 1] * __builtin_fma(ax[r], v1, vc[r]);
+                vp[r] = v1; vc[r] = v2;
+                acc[r] = __builtin_fma(apow, vc[r], acc[r]);
+            }
         }
     }
     // 2 a |x| <= 16 a: a <= 5e-3 (nodd <= 3) keeps the argument below 0.08
-    const double cs = (nodd <= 3) ? cos_tiny(2.0 * a * ax) : cos_small(2.0 * a * ax);
-    return __builtin_fma(E * ea2, cs, acc);
+    if (nodd <= 3) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) H[r] = __builtin_fma(E[r] * ea2, cos_tiny(2.0 * a * ax[r]), acc[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < N; ++r) H[r] = __builtin_fma(E[r] * ea2, cos_small(2.0 * a * ax[r]), acc[r]);
+    }
+}
+__device__ __forceinline__ double core_taylor_H_lds(double x, double a, double ea2, int nodd,
+                                                    const double* __restrict__ daw,
+                                                    const double* __restrict__ et) {
+    const double xs[1] = {x};
+    double H[1];
+    core_taylor_H_lds_n<1>(xs, a, ea2, nodd, daw, et, H);
+    return H[0];
 }
 
 // Core H(a,x), |x| < 7.2, 0 <= a < 7:  Alg. 916 real part

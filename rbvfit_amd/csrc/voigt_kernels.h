@@ -402,6 +402,9 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, rec_t rec, const d
 constexpr int TILE_THREADS_MAX = 256;   // tile_kernel: 1, 2 or 4 waves per workgroup
 constexpr int WALKER_THREADS_MAX = 1024; // walker_kernel: one wave per tile, up to 16 tiles per walker
 constexpr int FL_PAD = 10;        // LDS doubles after a tile's flux that the zero-padded taps may read
+#ifndef VP_CORE_ILP
+#define VP_CORE_ILP 2             // phase B of single-wave tiles in walker_kernel: flagged chunks evaluated side by side
+#endif
 constexpr int RB = 3;             // 64-pixel chunks per wave pass (register blocking / ILP); measured: RB=3
                                   // beats RB=2 and RB=4 by 3-5 %
 
@@ -501,6 +504,81 @@ __device__ __forceinline__ void core_chunk(const InstDev& I, rec_t lcw, double* 
     if (i < n_eval) fl[i] = (tau != tau) ? tau : exp_neg_tab(tau, etab);   // NaN survives (poisoned lines)
 }
 
+// N flagged chunks at once: per line of the UNION of their masks the core series runs for all of them side by side
+// (core_taylor_H_lds_n<N>: N times the instruction-level parallelism for a wave that has its SIMD to itself -- the
+// walker kernel's waves with line cores are the last ones running); a chunk that did not flag the line has its wing
+// value from phase A already and drops the result.  Per chunk the same operations in the same order as core_chunk:
+// bit-identical.
+template <bool GENERIC, int N>
+__device__ __forceinline__ void core_chunk_multi(const InstDev& I, rec_t lcw, double* __restrict__ fl,
+                                                 const unsigned long long* __restrict__ cm, int nwords, int q0, int n_eval,
+                                                 const int (&cc)[N], int lane, const double* __restrict__ daw,
+                                                 const double* __restrict__ etab) {
+    int i[N];
+    double gq[N], wq[N], tau[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        i[r] = cc[r] * 64 + lane;
+        const int ic = min(i[r], n_eval - 1);
+        const int q = min(max(q0 + ic, 0), I.P - 1);
+        gq[r] = I.ginv[q]; wq[r] = I.wave[q];
+        tau[r] = fl[ic];
+    }
+    for (int wd = 0; wd < nwords; ++wd) {
+        unsigned long long mr[N], m = 0ull;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const unsigned long long mw = cm[cc[r] * nwords + wd];
+            const unsigned int mlo = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)mw);
+            const unsigned int mhi = (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(mw >> 32));
+            mr[r] = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
+            m |= mr[r];
+        }
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            const int l = (wd << 6) + b;
+            m &= m - 1;
+            rec_t rec = lcw + (size_t)l * LC_STRIDE;
+            const int mode = rec_int(rec, LC_MODE, 0);
+            if (mode != 0) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    if ((mr[r] >> b) & 1ull) {
+                        if (GENERIC) tau[r] += cold_line_tau(wq[r], gq[r], rec);
+                        else tau[r] = __builtin_nan("");      // poisoned line (non-finite constants)
+                    }
+                }
+                continue;
+            }
+            double xf[N], h[N];
+            bool outside = false;
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                xf[r] = faithful_x(wq[r], gq[r], rec);
+                outside = outside || (fabs(xf[r]) >= X_CORE);
+            }
+            const int nodd = rec_int(rec, LC_MODE, 1);
+            core_taylor_H_lds_n<N>(xf, rec[LC_Y], rec[LC_EA2], nodd, daw, etab, h);
+            const double T = rec[LC_T];
+#pragma unroll
+            for (int r = 0; r < N; ++r) h[r] = T * h[r];
+            if (__ballot(outside) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    const double rw = wing_tau<NWING>(xf[r], rec + LC_K0);
+                    h[r] = (fabs(xf[r]) >= X_CORE) ? rw : h[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+                if ((mr[r] >> b) & 1ull) tau[r] += h[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+        if (i[r] < n_eval) fl[i[r]] = (tau[r] != tau[r]) ? tau[r] : exp_neg_tab(tau[r], etab);
+}
+
 // Synchronisation among the threads that share one tile.  SOLO: the tile belongs to ONE wave of a
 // larger workgroup (walker_kernel) and must not wait for the others: the LDS operations of a wave
 // execute in program order, so only the compiler has to be kept from reordering them.
@@ -594,12 +672,13 @@ __device__ __forceinline__ void lsf_block(const InstDev& I, const double* __rest
 // LANE's sum of chi^2 terms) or model flux written to `out` (OUT = 1 convolved, 2 unconvolved).  `first` (uniform):
 // the LDS tables (taps, exp table) are staged; a wave that works through several tiles in a row passes false from
 // its second tile on.  PRE: the tables' entries and the first pass's pixels come from `pre` (tile_preload, issued
-// before the records were needed); without it they are loaded here.
+// before the records were needed); without it they are loaded here.  PAIR (single-wave tiles): phase B takes the
+// flagged chunks VP_CORE_ILP at a time (core_chunk_multi).
 // `nthreads` threads (tid = 0..nthreads-1, whole waves) share the LDS block `fl`:
 //   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | exp table | per-chunk "line core" masks
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
 // fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
-template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true>
+template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false>
 __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
                                             int tid, int nthreads, const TilePre& pre, bool first,
                                             double* __restrict__ out, int out_stride) {
@@ -797,6 +876,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             dawson_to_lds(daw, tid, TILE_THREADS);   // staged only when some chunk needs the core series
             tile_sync<SOLO>();
             int kth = 0;
+            int hc0 = 0, hc1 = 0, nheld = 0;         // PAIR: flagged chunks waiting for partners (scalars, not an indexed array)
             for (int c = 0; c < nchunks; ++c) {
                 unsigned int any = 0u;
                 for (int wd = 0; wd < nwords; ++wd) {
@@ -804,8 +884,28 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                     any |= (unsigned int)mw | (unsigned int)(mw >> 32);
                 }
                 if (__builtin_amdgcn_readfirstlane(any) == 0u) continue;
+                if (PAIR) {
+                    if (nheld + 1 == VP_CORE_ILP) {
+                        int held[VP_CORE_ILP];
+                        held[0] = VP_CORE_ILP == 2 ? hc0 : hc0; held[1] = VP_CORE_ILP == 2 ? c : hc1; held[VP_CORE_ILP - 1] = c;
+                        core_chunk_multi<GENERIC, VP_CORE_ILP>(I, lcw, fl, cmask, nwords, q0, n_eval, held, lane, daw, etab);
+                        nheld = 0;
+                    } else {
+                        if (nheld == 0) hc0 = c; else hc1 = c;
+                        ++nheld;
+                    }
+                    continue;
+                }
                 if ((kth++ & (nwaves - 1)) != wid) continue;
                 core_chunk<GENERIC>(I, lcw, fl, cmask, nwords, q0, n_eval, c, lane, daw, etab);
+            }
+            if (PAIR) {
+                if (VP_CORE_ILP > 2 && nheld == 2) {
+                    const int h2[2] = {hc0, hc1};
+                    core_chunk_multi<GENERIC, 2>(I, lcw, fl, cmask, nwords, q0, n_eval, h2, lane, daw, etab);
+                } else if (nheld == 1) {
+                    core_chunk<GENERIC>(I, lcw, fl, cmask, nwords, q0, n_eval, hc0, lane, daw, etab);
+                }
             }
         }
         tile_sync<SOLO>();
@@ -1066,7 +1166,7 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
         // can be scheduled above it
         unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
         asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-        const double wsum = wave_sum(tile_work<METHOD, 0, false, true>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0));
+        const double wsum = wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0));
         if (lane == 0) red[wid] = wsum;
         __syncthreads();
         if (wid != 0) return;
