@@ -1018,6 +1018,14 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
     return VP_OK;
 }
 
+#ifdef VP_STAMPS
+// diagnostic build only: the walker kernel's phase stamps of the last launch (shader clock), (walker, wave, stage)
+extern "C" int vp_debug_read_stamps(long long* out, int n) {
+    const size_t bytes = sizeof(long long) * (size_t)std::min(n, vp::STAMP_W * vp::STAMP_WAVES * vp::STAMP_STAGES);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vp::g_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 void vp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     const vp::Philox4 r = vp::philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
     for (int i = 0; i < 4; ++i) out[i] = r.v[i];

@@ -402,6 +402,24 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, rec_t rec, const d
 constexpr int TILE_THREADS_MAX = 256;   // tile_kernel: 1, 2 or 4 waves per workgroup
 constexpr int WALKER_THREADS_MAX = 1024; // walker_kernel: one wave per tile, up to 16 tiles per walker
 constexpr int FL_PAD = 10;        // LDS doubles after a tile's flux that the zero-padded taps may read
+// Diagnostic build (-DVP_STAMPS, scripts/walker_timeline.py): every wave of walker_kernel leaves the shader clock at its
+// phase boundaries in g_stamps[walker][wave][stage]; read back with vp_debug_read_stamps.  Not compiled otherwise.
+#ifdef VP_STAMPS
+constexpr int STAMP_W = 1024, STAMP_WAVES = 16, STAMP_STAGES = 8;
+__device__ long long g_stamps[STAMP_W * STAMP_WAVES * STAMP_STAGES];
+#define VP_STAMP(stage) do { if (g_stamp_w >= 0 && g_stamp_w < STAMP_W && (threadIdx.x & 63) == 0) \
+    g_stamps[(g_stamp_w * STAMP_WAVES + (int)(threadIdx.x >> 6)) * STAMP_STAGES + (stage)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define VP_STAMP_DECL const int g_stamp_w = (int)blockIdx.x;
+#define VP_STAMP_ARG , const int g_stamp_w
+#define VP_STAMP_PASS , g_stamp_w
+#define VP_STAMP_NONE , -1
+#else
+#define VP_STAMP(stage) do { } while (0)
+#define VP_STAMP_DECL
+#define VP_STAMP_ARG
+#define VP_STAMP_PASS
+#define VP_STAMP_NONE
+#endif
 #ifndef VP_CORE_ILP
 #define VP_CORE_ILP 2             // phase B of single-wave tiles in walker_kernel: flagged chunks evaluated side by side
 #endif
@@ -681,7 +699,7 @@ __device__ __forceinline__ void lsf_block(const InstDev& I, const double* __rest
 template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false>
 __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
                                             int tid, int nthreads, const TilePre& pre, bool first,
-                                            double* __restrict__ out, int out_stride) {
+                                            double* __restrict__ out, int out_stride VP_STAMP_ARG) {
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
     const int lane = SOLO ? tid : (tid & 63), wid = SOLO ? 0 : (tid >> 6);     // SOLO: tid IS the lane
@@ -854,6 +872,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
         }
     }
     tile_sync<SOLO>();
+    VP_STAMP(2);
 
     // ---- phase B: line cores.  The flagged chunks of the tile are dealt round-robin to the
     //      waves (balanced whatever their position), each chunk finished by one wave (core_chunk).
@@ -875,6 +894,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
         if (anyc) {
             dawson_to_lds(daw, tid, TILE_THREADS);   // staged only when some chunk needs the core series
             tile_sync<SOLO>();
+            VP_STAMP(6);
             int kth = 0;
             int hc0 = 0, hc1 = 0, nheld = 0;         // PAIR: flagged chunks waiting for partners (scalars, not an indexed array)
             for (int c = 0; c < nchunks; ++c) {
@@ -910,6 +930,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
         }
         tile_sync<SOLO>();
     }
+    VP_STAMP(3);
 
     // ---- LSF from LDS, chi^2 term, reduce ------------------------------------------------------
     //      Each lane produces TWO adjacent output pixels from a sliding window of the flux held in
@@ -933,6 +954,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }
+    VP_STAMP(4);
     return acc;
 }
 
@@ -990,11 +1012,11 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
         InstDev J = I;
         J.line_sel = blockIdx.z;
         tile_work<METHOD, OUT, GENERIC, false>(J, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x, pre, true,
-                                               out + (size_t)blockIdx.z * I.P, out_stride);
+                                               out + (size_t)blockIdx.z * I.P, out_stride VP_STAMP_NONE);
         return;
     }
     const double wsum = wave_sum(tile_work<METHOD, OUT, GENERIC, false>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x, pre, true,
-                                                                        out, out_stride));
+                                                                        out, out_stride VP_STAMP_NONE));
     if (OUT == 0) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
         double* red = fl + I.span + FL_PAD;
@@ -1112,6 +1134,8 @@ template <int METHOD, bool CLUSTERS, bool SAMPLER>   // CLUSTERS: the instrument
 #endif
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A, StretchArgs S) {
     extern __shared__ double smem[];
+    VP_STAMP_DECL
+    VP_STAMP(0);
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler knows it: the tile
                                                                    // geometry stays in SGPRs as in tile_kernel
@@ -1155,6 +1179,7 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
                                                                            // staged while it waits for the records anyway
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    VP_STAMP(1);
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
     if (oobw && !SAMPLER) {
         if (tid == 0) A.lnprob[w] = -__builtin_inf();
@@ -1166,9 +1191,10 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
         // can be scheduled above it
         unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
         asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-        const double wsum = wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0));
+        const double wsum = wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS));
         if (lane == 0) red[wid] = wsum;
         __syncthreads();
+        VP_STAMP(5);
         if (wid != 0) return;
         double sk = 0.0;
         for (int k = 0; k < nw; ++k) sk += red[k];
