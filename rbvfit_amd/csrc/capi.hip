@@ -606,6 +606,12 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
+    {
+        const std::vector<int> zeros(vp::WALKER_THREADS_MAX / 64, 0);
+        int* d_hint;
+        if ((rc = upload<int>(c, &in, zeros.data(), zeros.size(), &d_hint))) { for (void* p : in.allocs) hipFree(p); return rc; }
+        d.core_hint = d_hint;
+    }
     in.dev_s = d;                                        // one-pass tiles for small batches (same LDS layout rules)
     {
         const int span_s = 64 * vp::RB * nwaves;

@@ -76,6 +76,9 @@ struct InstDev {
     const double* flux;
     const double* w;       // inv_sigma2
     const double* kflip;   // taps flipped (and normalised for the astropy branch): out[p] = sum_j kflip[j] f[p-halo_lo+j]
+    int* core_hint;        // (16) walker_kernel: tile t met line cores in an earlier launch -> its wave stages the Dawson
+                           // table while it waits for the records instead of between phase A and phase B (a hint only:
+                           // results never depend on it)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -699,7 +702,7 @@ __device__ __forceinline__ void lsf_block(const InstDev& I, const double* __rest
 template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false>
 __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
                                             int tid, int nthreads, const TilePre& pre, bool first,
-                                            double* __restrict__ out, int out_stride VP_STAMP_ARG) {
+                                            double* __restrict__ out, int out_stride VP_STAMP_ARG, bool daw_ready = false) {
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
     const int lane = SOLO ? tid : (tid & 63), wid = SOLO ? 0 : (tid >> 6);     // SOLO: tid IS the lane
@@ -892,7 +895,10 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             anyc = __ballot(anycore != 0u) != 0ull;
         }
         if (anyc) {
-            dawson_to_lds(daw, tid, TILE_THREADS);   // staged only when some chunk needs the core series
+            if (!daw_ready) {                        // staged only when some chunk needs the core series
+                dawson_to_lds(daw, tid, TILE_THREADS);
+                if (SOLO && tid == 0) I.core_hint[p0 / I.TP] = 1;      // (walker_kernel: next time, ahead of the records)
+            }
             tile_sync<SOLO>();
             VP_STAMP(6);
             int kth = 0;
@@ -1040,6 +1046,11 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
 // ~350 per record lane: this sits on the critical path of the walker's workgroup.
 __device__ __forceinline__ void prep_record_lanes(double thv, const LinesDev& T, int l0, double* __restrict__ lcw, int lane) {
     const int j = lane >> 4, slot = lane & 15, l = min(l0 + j, T.L - 1);
+    // the wing-series constants of this lane's coefficient do not depend on theta: requested first, so that they travel
+    // with the theta row instead of costing a memory round trip of their own behind it
+    double wc[NWING];
+#pragma unroll
+    for (int i = 0; i < NWING; ++i) wc[i] = g_wing.c[min(slot, NWING - 1)][i];
     // the theta row lives across the lanes (thv = theta[lane], D <= 64) and the three parameters of the line are
     // picked with lane shuffles: the index tables are fetched beside it, one memory round trip instead of index -> theta
     const int iN = T.N_idx[l], ib = T.b_idx[l], iv = T.v_idx[l];
@@ -1052,11 +1063,9 @@ __device__ __forceinline__ void prep_record_lanes(double thv, const LinesDev& T,
         const double a2 = a * a;
         const double pref = Tl * (a * INV_SQRT_PI);
         double cm = 0.0;
-#pragma unroll 7                                       // (7 coefficient loads in flight at a time: registers)
-        for (int i = NWING - 1; i >= 0; --i) {
-            const double c = g_wing.c[slot][i];        // (zero above the diagonal; not used there)
-            cm = (i <= slot) ? __builtin_fma(cm, a2, c) : cm;
-        }
+#pragma unroll
+        for (int i = NWING - 1; i >= 0; --i)           // (zero above the diagonal; not used there)
+            cm = (i <= slot) ? __builtin_fma(cm, a2, wc[i]) : cm;
         rec[LC_K0 + slot] = pref * cm;
     } else if (slot == 14) {
         rec[LC_A] = s.Ax;
@@ -1177,6 +1186,9 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
     const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
     fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = g_exp2_64[lane];   // the wave's exp table (EXP_LDS_DOUBLES = 64 entries),
                                                                            // staged while it waits for the records anyway
+    // ... and the Dawson table where the tile met line cores before (1.2 us between phase A and phase B otherwise)
+    const bool daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(I.core_hint[wid]) != 0;
+    if (daw_ready) dawson_to_lds(fl + I.span + FL_PAD + 4, lane, 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     VP_STAMP(1);
@@ -1191,7 +1203,7 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
         // can be scheduled above it
         unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
         asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-        const double wsum = wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS));
+        const double wsum = wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS, daw_ready));
         if (lane == 0) red[wid] = wsum;
         __syncthreads();
         VP_STAMP(5);
