@@ -896,6 +896,9 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
         }
         if (anyc) {
             if (!daw_ready) {                        // staged only when some chunk needs the core series
+#ifndef VP_NO_PRIO
+                if (SOLO) __builtin_amdgcn_s_setprio(2);
+#endif
                 dawson_to_lds(daw, tid, TILE_THREADS);
                 if (SOLO && tid == 0) I.core_hint[p0 / I.TP] = 1;      // (walker_kernel: next time, ahead of the records)
             }
@@ -1192,6 +1195,11 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     VP_STAMP(1);
+#ifndef VP_NO_PRIO
+    // the tiles with line cores are the workgroup's critical path (twice the work of the others): their waves go first
+    // on their SIMDs from the start where the hint says so, from phase B on otherwise
+    if (daw_ready) __builtin_amdgcn_s_setprio(2);
+#endif
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
     if (oobw && !SAMPLER) {
         if (tid == 0) A.lnprob[w] = -__builtin_inf();
