@@ -285,11 +285,11 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
 // walker_kernel: the whole batch in ONE launch (workgroup = walker, wave = tile).  Possible for a single
 // instrument with single-wave tiles, at most 16 of them, whose prior box keeps every line in the fast
 // domain.  A walker's workgroup holds 12 wave slots of one CU for as long as its slowest tile runs, two fit on a
-// CU, so the launch time is a step function of ceil(W / 512 workgroup places): measured on C1 (us per pass,
-// walker kernel / prep + tile + finalize launches) 64: 23.1 / 22.3, 128: 23.1 / 23.6, 256: 23.2 / 25.2,
-// 384: 30.8 / 30.3, 512: 30.9 / 33.1, 768: 46.5 / ~41, 1024: 57 / 48.5.  By default it is therefore used for one
-// layer of >= 40 % of the CUs or a second layer of >= 60 %; larger batches keep the one-wave workgroups, whose slots
-// the hardware refills one by one as tiles finish.
+// CU, so the launch time is a step function of the number of 256-workgroup layers: measured on C1 (us per pass,
+// walker kernel / prep + tile + finalize launches) 64: 18.2 / 22.3, 128: 18.3 / 23.5, 256: 18.3 / 24.9,
+// 320: 24.8 / 26.9, 384: 24.8 / 29.3, 512: 25.0 / 31.0, 640: 38.5 / 35.5, 768: 38.9 / 36.4, 1024: 47.3 / 43.1.
+// By default it is therefore used whenever the batch fits the CUs at once (at most two layers); larger batches keep
+// the one-wave workgroups, whose slots the hardware refills one by one as tiles finish.
 size_t walker_lds_bytes(const Instrument& in) { return (size_t)in.dev.ntiles * in.lds_bytes + (in.dev.ntiles + 2) * sizeof(double); }
 
 bool walker_applies(const vp_ctx* c, int W) {
@@ -303,8 +303,8 @@ bool walker_applies(const vp_ctx* c, int W) {
     // a CU holds per_cu walker workgroups at once (24 wave slots / waves per walker, LDS permitting); the batch lies
     // on the 256 CUs in layers of 256 workgroups and the launch takes as long as the fullest CU's layers
     const int per_cu = std::max(1, std::min(24 / std::max(1, in.dev.ntiles), (int)(c->lds_limit / walker_lds_bytes(in))));
-    const int layers = (W + 255) / 256, last = W - (layers - 1) * 256;
-    return layers <= std::min(per_cu, 2) && last * 10 >= 256 * (layers == 1 ? 4 : 6);
+    const int layers = (W + 255) / 256;
+    return layers <= std::min(per_cu, 2);
 }
 
 void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {

@@ -897,7 +897,10 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
         if (anyc) {
             if (!daw_ready) {                        // staged only when some chunk needs the core series
 #ifndef VP_NO_PRIO
-                if (SOLO) __builtin_amdgcn_s_setprio(2);
+                // a wave with line cores has about twice the work of one without: it goes first on its SIMD from here on
+                // (walker_kernel: the workgroup's critical path; single-wave tile workgroups: longest jobs first,
+                // C1 at 1024 walkers 44.6 -> 43.0 us, neutral at 8192 and on C2-C4)
+                if (SOLO || nwaves == 1) __builtin_amdgcn_s_setprio(2);
 #endif
                 dawson_to_lds(daw, tid, TILE_THREADS);
                 if (SOLO && tid == 0) I.core_hint[p0 / I.TP] = 1;      // (walker_kernel: next time, ahead of the records)

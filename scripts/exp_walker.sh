@@ -18,4 +18,4 @@ print('$label', d['config']['walkers_per_gpu'], round(d['value']), round(1e3*d['
 WS="${WS:-64 128 256 512 1024 2048 8192}"
 run launches RBVFIT_AMD_WALKER=0 -- $WS
 run walker RBVFIT_AMD_WALKER=1 -- $WS
-run walker_coop RBVFIT_AMD_WALKER=1 RBVFIT_AMD_WALKER_COOP=1 -- $WS
+

@@ -19,7 +19,14 @@ def test_chain_lnprob_is_the_posterior_of_the_chain_positions():
     eng, p0 = wl.engine, wl.thetas
     pos, lp, chain, clp, nacc = eng.stretch_run(p0, 25, seed=3)
     assert chain.shape == (25, 48, 6) and clp.shape == (25, 48)
+    # the half-steps ran in the one-launch walker kernel, whose tiles are the full-size ones: the same tiles give the
+    # same bits whatever the batch; the small tiles a 1200-row batch of this 512-pixel spectrum would get by default
+    # group the chi^2 sum differently (last-bit differences)
+    ref_default = eng.lnprob(chain.reshape(-1, 6)).reshape(25, 48)
+    np.testing.assert_allclose(clp, ref_default, rtol=1e-14, atol=0)
+    eng.set_option("geom", 0)
     ref = eng.lnprob(chain.reshape(-1, 6)).reshape(25, 48)
+    eng.set_option("geom", -1)
     np.testing.assert_array_equal(clp, ref)                      # same kernels, any batch composition
     np.testing.assert_array_equal(pos, chain[-1]); np.testing.assert_array_equal(lp, clp[-1])
     assert np.all(chain >= wl.lb) and np.all(chain <= wl.ub)    # out-of-box proposals are never accepted
