@@ -471,12 +471,23 @@ __device__ __forceinline__ void multipole_rb(const double (&y)[RB], rec_t Q, dou
 struct Eager {            // prefetched one line ahead: what the tier decision needs.  (Fetching K0..K5 along with it, so
     double A, B;          // that the far tiers issue no load behind their decision, measured 0.5-2 % SLOWER on C1-C4:
     int mode, mp, cl_end; // the exposed scalar-load latency is covered by the other waves, the 20 extra SGPR spills are not.)
+    int touch1, touch2;   // TOUCH (walker_kernel): see load_eager
 };
+template <bool TOUCH>
 __device__ __forceinline__ Eager load_eager(rec_t rec) {
     Eager e;
     e.A = rec[LC_A];
     e.B = rec[LC_B];
     e.mode = rec_int(rec, LC_MODE, 0);
+    e.touch1 = 0; e.touch2 = 0;
+    if (TOUCH) {
+        // pull the record's second and third 64-byte lines (K6..K13; the faithful-x constants) into the scalar cache
+        // with this prefetch: the loads behind a tier decision then hit.  (Two dwords nobody computes with; they are
+        // "used" one line later, when they have long arrived, so that the compiler keeps the loads.)  Worth 0.3 us of
+        // 18.3 in the latency-bound walker kernel; costs 1-3 % where the SIMDs are full (tile_kernel: off).
+        e.touch1 = rec_int(rec, 8, 0);
+        e.touch2 = rec_int(rec, 16, 0);
+    }
     e.mp = rec_int(rec, LC_CL, 0);
     e.cl_end = rec_int(rec, LC_CL, 1);
     return e;
@@ -746,7 +757,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
 #pragma unroll
                 for (int r = 0; r < RB; ++r) todo[r] = 0ull;
                 const int l1 = min(I.L, l0 + 64);
-                Eager nxt = load_eager(lcw + (size_t)l0 * LC_STRIDE);
+                Eager nxt = load_eager<SOLO>(lcw + (size_t)l0 * LC_STRIDE);
                 for (int l = l0; l < l1; ++l) {
                     // far from a whole cluster of components?  one multipole evaluation replaces all of
                     // its member lines (only tried at the first line of a cluster that fits this block)
@@ -781,17 +792,18 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                                 multipole_rb<MP_J0>(y, mrec + MP_Q0, tau);
                             }
                             l = nxt.cl_end - 1;                        // skip the member lines
-                            nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
+                            nxt = load_eager<SOLO>(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
                             continue;
                         }
                     }
                     const Eager cur = nxt;
+                    if (SOLO) asm volatile("" :: "s"(cur.touch1), "s"(cur.touch2));
                     if (I.line_sel >= 0 && l != I.line_sel) {
-                        nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
+                        nxt = load_eager<SOLO>(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
                         continue;
                     }
                     rec_t rec = lcw + (size_t)l * LC_STRIDE;
-                    nxt = load_eager(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);   // scalar prefetch of the next line
+                    nxt = load_eager<SOLO>(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);   // scalar prefetch of the next line
                     const unsigned long long bit = 1ull << (l - l0);
                     const double A = cur.A, B = cur.B;
                     rec_t K = rec + LC_K0;
