@@ -791,7 +791,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                             } else {
                                 multipole_rb<MP_J0>(y, mrec + MP_Q0, tau);
                             }
-                            l = nxt.cl_end - 1;                        // skip the member lines
+                            l = max(l, nxt.cl_end - 1);                // skip the member lines (never backwards, whatever a record holds)
                             nxt = load_eager<SOLO>(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
                             continue;
                         }
