@@ -75,6 +75,10 @@ struct Instrument {
     std::vector<int> h_bidx;
     bool needs_generic = true;
     int nwaves = 1;              // waves per tile workgroup (1, 2 or 4)
+    std::vector<double> h_lines; // lambda0 | gamma | f | zfac: with h_idx, what the line records of a walker depend on
+    std::vector<int> h_idx;      // N_idx | b_idx | v_idx | method | multipole settings
+    bool same_lines_as_prev = false;   // this instrument's records ARE the previous instrument's (same line tables):
+                                       // its record-preparation launch is skipped (C3: two instruments, one physics)
 };
 
 }  // namespace
@@ -364,8 +368,11 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
-        if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-        launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr, s);
+        if (!(k > 0 && in.same_lines_as_prev)) {       // (same line tables as the previous instrument: its records and
+                                                       // generic-path flags are still in the workspace)
+            if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
+            launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr, s);
+        }
         size_t m1 = prof ? prof_mark(c, s) : 0;
         const vp::InstDev& geom = sel ? in.dev_s : in.dev;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin,
@@ -629,6 +636,15 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     }
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
     in.h_lambda0.assign(lambda0, lambda0 + L); in.h_gamma.assign(gamma, gamma + L); in.h_bidx.assign(b_idx, b_idx + L);
+    in.h_lines.assign(lambda0, lambda0 + L); in.h_lines.insert(in.h_lines.end(), gamma, gamma + L);
+    in.h_lines.insert(in.h_lines.end(), f, f + L); in.h_lines.insert(in.h_lines.end(), zfac, zfac + L);
+    in.h_idx.assign(N_idx, N_idx + L); in.h_idx.insert(in.h_idx.end(), b_idx, b_idx + L); in.h_idx.insert(in.h_idx.end(), v_idx, v_idx + L);
+    in.h_idx.push_back(voigt_method); in.h_idx.push_back(c->tune.no_multipole); in.h_idx.push_back(c->tune.multipole_min);
+    if (!c->inst.empty()) {
+        const Instrument& pv = c->inst.back();
+        in.same_lines_as_prev = pv.h_idx == in.h_idx && pv.h_lines.size() == in.h_lines.size() &&
+                                std::memcmp(pv.h_lines.data(), in.h_lines.data(), in.h_lines.size() * sizeof(double)) == 0;
+    }
     analyse_generic(c, in);
     if (c->tune.lds_pad > 0) in.lds_bytes += (size_t)c->tune.lds_pad;   // occupancy experiments
     c->inst.push_back(std::move(in));

@@ -130,3 +130,46 @@ def test_more_than_64_and_128_lines():
         np.testing.assert_allclose(got, vo.lnprob_batch(thetas, lb, ub, [inst]), rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
         for i in range(2):
             np.testing.assert_allclose(fl[i], vo.model_flux(od, thetas[i], wave), rtol=0, atol=FLUX_ATOL)
+
+
+def test_instruments_sharing_or_not_sharing_their_line_tables():
+    """Three instruments on one parameter vector: B has A's line tables (its record-preparation launch is skipped, A's
+    records are reused), C differs from B in the Voigt method only (records must be made again).  Every order of
+    adding them agrees with the oracle."""
+    import itertools
+    import rbvfit_amd
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    rng = np.random.default_rng(5)
+    cfg = FitConfiguration()
+    cfg.add_system(0.348, "MgII", [2796.352, 2803.531], 3)
+    cfg.add_system(0.349, "FeII", [2600.1729, 2586.650], 2)
+    C = cfg.total_components
+    theta = np.concatenate([rng.uniform(12.5, 14.0, C), rng.uniform(6, 30, C), rng.uniform(-100, 100, C)])
+    lb = np.concatenate([np.full(C, 10.0), np.full(C, 1.0), np.full(C, -400.0)])
+    ub = np.concatenate([np.full(C, 18.0), np.full(C, 150.0), np.full(C, 400.0)])
+    thetas = np.clip(theta + 0.05 * rng.standard_normal((5, 3 * C)), lb + 1e-9, ub - 1e-9)
+    specs = [("wofz", "6.5", np.linspace(3755.0, 3795.0, 1500)),
+             ("wofz", "3.0", np.linspace(3480.0, 3515.0, 1100)),
+             ("fast", "3.0", np.linspace(3765.0, 3790.0, 900))]
+    built = []
+    for method, fwhm, wave in specs:
+        data = VoigtModel(cfg, FWHM=fwhm, voigt_method=method).compile().data
+        od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors, data.N_indices,
+                                data.b_indices, data.v_indices, data.taps, data.lsf_mode, data.voigt_method)
+        err = np.full(wave.size, 0.04)
+        flux = vo.model_flux(od, thetas[0], wave) + rng.normal(0, 0.04, wave.size)
+        built.append((data, vo.OracleInstrument.from_error(od, wave, flux, err), wave, flux))
+    for order in itertools.permutations(range(3)):
+        insts = [built[k][1] for k in order]
+        ref = vo.lnprob_batch(thetas, lb, ub, insts)
+        with rbvfit_amd.Engine(0) as e:
+            e.set_bounds(lb, ub)
+            for k in order:
+                data, oi, wave, flux = built[k]
+                e.add_instrument(wave, flux, oi.inv_sigma2, oi.log_inv_sigma2, **data.engine_kwargs())
+            got = e.lnprob(thetas)
+            e.set_option("geom", 0); e.set_option("finalize", 0)
+            got_big = e.lnprob(thetas)
+        np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL, err_msg=str(order))
+        np.testing.assert_allclose(got_big, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL, err_msg=str(order))
