@@ -37,6 +37,8 @@ struct Tuning {
     int waves = 0;              // waves per tile workgroup, 0 = default (read when an instrument is added)
     long lds_pad = 0;           // extra LDS bytes per tile workgroup: occupancy experiments
     int no_fused_accept = 0;    // device sampler: separate accept / propose launches
+    int farfield = -1;          // far-field expansions in the tile launches: -1 for instruments with >= 8 lines, 0 never,
+                                // 1 whenever possible (read when an instrument is added)
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
 
@@ -49,6 +51,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0),
+    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -75,6 +78,7 @@ struct Instrument {
     std::vector<int> h_bidx;
     bool needs_generic = true;
     int nwaves = 1;              // waves per tile workgroup (1, 2 or 4)
+    bool ff_on = false;          // far-field expansions (farfield_kernel + the FF instance of tile_kernel) for lnprob
     std::vector<double> h_lines; // lambda0 | gamma | f | zfac: with h_idx, what the line records of a walker depend on
     std::vector<int> h_idx;      // N_idx | b_idx | v_idx | method | multipole settings
     bool same_lines_as_prev = false;   // this instrument's records ARE the previous instrument's (same line tables):
@@ -105,6 +109,8 @@ struct vp_ctx {
     int* d_flags = nullptr;      // (capW)
     unsigned int* d_ticket = nullptr;  // (capW) arrival counters of the fused final reduction
     int* d_genflag = nullptr;    // (capW) walkers with lines outside the fast domain (per instrument pass)
+    double* d_ff = nullptr;      // (capW, cap_ffblk, FF_STRIDE) far-field expansions of the instrument being evaluated
+    int cap_ffblk = 0;
     std::vector<double> h_lb;    // host copy of the lower bounds
     int* d_tile_off = nullptr;   // 2 x (n_inst + 1): tile offsets of the full-size and of the one-pass geometry
     double* d_sum_logw = nullptr;
@@ -206,13 +212,19 @@ int ensure_workspace(vp_ctx* c, int W) {
         HIP_TRY(c, hipMemcpy(c->d_sum_logw, slw.data(), slw.size() * sizeof(double), hipMemcpyHostToDevice));
         c->meta_dirty = false;
     }
-    if (W <= c->capW && maxL <= c->capL && c->total_tiles <= c->cap_tiles) return VP_OK;
+    int ffblk = 0;
+    for (auto& in : c->inst)
+        if (in.ff_on) ffblk = std::max({ffblk, in.dev.ntiles * in.dev.ff_nblk, in.dev_s.ntiles * in.dev_s.ff_nblk});
+    if (W <= c->capW && maxL <= c->capL && c->total_tiles <= c->cap_tiles && ffblk <= c->cap_ffblk) return VP_OK;
     // a stream-ordered previous call may still be using the old buffers
     HIP_TRY(c, hipDeviceSynchronize());
     const int newW = std::max(W, c->capW);
-    for (void* p : {(void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial, (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag})
+    for (void* p : {(void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial, (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag,
+                    (void*)c->d_ff})
         if (p) HIP_TRY(c, hipFree(p));
     c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->d_ticket = nullptr; c->d_genflag = nullptr; c->capW = 0;
+    c->d_ff = nullptr; c->cap_ffblk = 0;
+    if (ffblk > 0) HIP_TRY(c, hipMalloc((void**)&c->d_ff, (size_t)newW * ffblk * vp::FF_STRIDE * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_theta, (size_t)newW * std::max(c->D, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_out, (size_t)newW * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_lc, (size_t)newW * maxL * vp::LC_STRIDE * sizeof(double)));
@@ -223,17 +235,23 @@ int ensure_workspace(vp_ctx* c, int W) {
     HIP_TRY(c, hipMemset(c->d_ticket, 0, (size_t)newW * sizeof(unsigned int)));
     HIP_TRY(c, hipMalloc((void**)&c->d_genflag, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMemset(c->d_genflag, 0, (size_t)newW * sizeof(int)));
-    c->capW = newW; c->capL = maxL; c->cap_tiles = c->total_tiles;
+    c->capW = newW; c->capL = maxL; c->cap_tiles = c->total_tiles; c->cap_ffblk = ffblk;
     return VP_OK;
 }
 
 template <int OUT, bool GENERIC>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
                  int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag, const vp::InstDev* geom = nullptr,
-                 int grid_z = 1) {
+                 int grid_z = 1, double* ff = nullptr) {
     const vp::InstDev& dev = geom ? *geom : in.dev;
     dim3 grid(W, dev.ntiles, grid_z);
     dim3 block(64 * in.nwaves);
+    if (ff && OUT == 0 && !GENERIC && dev.method == VP_VOIGT_WOFZ) {     // far lines from the blocks' expansions
+        vp::InstDev d2 = dev;
+        d2.ff = ff;
+        hipLaunchKernelGGL((vp::tile_kernel<0, 0, false, true>), grid, block, in.lds_bytes, s, d2, lc, flags, out, stride, offset, fin, genflag);
+        return;
+    }
     if (dev.method == VP_VOIGT_FAST) {
         if (!GENERIC)
             hipLaunchKernelGGL((vp::tile_kernel<1, OUT, false>), grid, block, in.lds_bytes, s, dev, lc, flags, out,
@@ -373,10 +391,17 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
             launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr, s);
         }
-        size_t m1 = prof ? prof_mark(c, s) : 0;
         const vp::InstDev& geom = sel ? in.dev_s : in.dev;
+        double* ff = (in.ff_on && c->d_ff) ? c->d_ff : nullptr;
+        if (ff) {                                        // the blocks' far-field expansions from the records just made
+            vp::InstDev g2 = geom;
+            g2.ff = ff;
+            const int nbk = geom.ntiles * geom.ff_nblk;
+            hipLaunchKernelGGL(vp::farfield_kernel, dim3((nbk + 63) / 64, W), dim3(64), 0, s, g2, in.lines, c->d_lc, W);
+        }
+        size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin,
-                              gen ? c->d_genflag : (const int*)nullptr, &geom);
+                              gen ? c->d_genflag : (const int*)nullptr, &geom, 1, ff);
         if (gen)
             launch_tile<0, true>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin, c->d_genflag, &geom);
         if (prof) {
@@ -490,7 +515,8 @@ int vp_ctx_destroy(vp_ctx* c) {
     hipDeviceSynchronize();
     for (auto& in : c->inst) for (void* p : in.allocs) hipFree(p);
     for (void* p : {(void*)c->d_lb, (void*)c->d_ub, (void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial,
-                    (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch})
+                    (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch,
+                    (void*)c->d_ff})
         if (p) hipFree(p);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -619,12 +645,39 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         if ((rc = upload<int>(c, &in, zeros.data(), zeros.size(), &d_hint))) { for (void* p : in.allocs) hipFree(p); return rc; }
         d.core_hint = d_hint;
     }
+    d.ff_tab = nullptr; d.ff = nullptr; d.ff_nblk = 0;
     in.dev_s = d;                                        // one-pass tiles for small batches (same LDS layout rules)
     {
         const int span_s = 64 * vp::RB * nwaves;
         if (span_s < d.span && span_s - (Kuse - 1) >= 64) {
             in.dev_s.span = span_s; in.dev_s.TP = span_s - (Kuse - 1);
             in.dev_s.ntiles = (P + in.dev_s.TP - 1) / in.dev_s.TP;
+        }
+    }
+    // far-field expansions: per block of 64 RB evaluated pixels the centre and half-width of 1/wave (both geometries)
+    in.ff_on = voigt_method == VP_VOIGT_WOFZ && L <= 128 && (c->tune.farfield > 0 || (c->tune.farfield < 0 && L >= 8));
+    if (in.ff_on) {
+        for (vp::InstDev* gd : {&in.dev, &in.dev_s}) {
+            const int blk_px = 64 * vp::RB, nblk = (gd->span + blk_px - 1) / blk_px;
+            std::vector<double> tab((size_t)gd->ntiles * nblk * 4, 0.0);
+            for (int t = 0; t < gd->ntiles; ++t) {
+                const int p0 = t * gd->TP, nout = std::min(p0 + gd->TP, P) - p0, n_eval = nout + Kuse - 1, q0 = p0 - gd->halo_lo;
+                for (int b = 0; b < nblk; ++b) {
+                    double* e = tab.data() + ((size_t)t * nblk + b) * 4;
+                    const int i0 = b * blk_px;
+                    if (i0 >= n_eval) { e[0] = 0.0; e[1] = -1.0; e[2] = 0.0; e[3] = 0.0; continue; }
+                    const int i1 = std::min(i0 + blk_px, n_eval) - 1;
+                    const int qa = std::min(std::max(q0 + i0, 0), P - 1), qb = std::min(std::max(q0 + i1, 0), P - 1);
+                    double gmin = ginv[qa], gmax = ginv[qa];
+                    for (int q = qa; q <= qb; ++q) { gmin = std::min(gmin, ginv[q]); gmax = std::max(gmax, ginv[q]); }
+                    const double gc = 0.5 * (gmax + gmin), hw = 0.5 * (gmax - gmin);
+                    e[0] = gc; e[1] = hw; e[2] = hw > 0.0 ? 1.0 / hw : 0.0; e[3] = gc * e[2];
+                    if (!(hw >= 0.0) || !(std::fabs(gc) <= 1.79e308)) { e[1] = -1.0; e[2] = 0.0; e[3] = 0.0; }   // NaN pixels: no expansion
+                }
+            }
+            double* d_tab;
+            if ((rc = upload<double>(c, &in, tab.data(), tab.size(), &d_tab))) { for (void* p : in.allocs) hipFree(p); return rc; }
+            gd->ff_tab = d_tab; gd->ff_nblk = nblk; gd->ff = nullptr;
         }
     }
     in.lds_bytes = (size_t)(span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
@@ -1041,6 +1094,12 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
 }
 
 #ifdef VP_STAMPS
+// diagnostic build only: the far-field workspace of the last lnprob launch (doubles)
+extern "C" int vp_debug_read_ff(vp_ctx* c, double* out, long n) {
+    if (!c || !c->d_ff) return -1;
+    hipDeviceSynchronize();
+    return hipMemcpy(out, c->d_ff, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
 // diagnostic build only: the walker kernel's phase stamps of the last launch (shader clock), (walker, wave, stage)
 extern "C" int vp_debug_read_stamps(long long* out, int n) {
     const size_t bytes = sizeof(long long) * (size_t)std::min(n, vp::STAMP_W * vp::STAMP_WAVES * vp::STAMP_STAGES);

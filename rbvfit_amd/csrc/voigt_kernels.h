@@ -76,6 +76,12 @@ struct InstDev {
     const double* flux;
     const double* w;       // inv_sigma2
     const double* kflip;   // taps flipped (and normalised for the astropy branch): out[p] = sum_j kflip[j] f[p-halo_lo+j]
+    // far-field expansions (FF instance of tile_kernel, see farfield_kernel): per block of 64*RB evaluated pixels
+    // [g_c, hw, 1/hw, g_c/hw] of 1/wave over the block (instrument tables, ntiles x ff_nblk x 4), and the per-launch
+    // workspace (W, ntiles x ff_nblk, FF_STRIDE) of expansion coefficients + masks of the lines they cover
+    const double* ff_tab;
+    double* ff;
+    int ff_nblk;           // blocks per tile = ceil(span / (64 RB))
     int* core_hint;        // (16) walker_kernel: tile t met line cores in an earlier launch -> its wave stages the Dawson
                            // table while it waits for the records instead of between phase A and phase B (a hint only:
                            // results never depend on it)
@@ -400,6 +406,162 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, rec_t rec, const d
 }
 
 // ---------------------------------------------------------------------------------------------
+// far-field expansions
+// ---------------------------------------------------------------------------------------------
+// Far from a line (every |x| of the block >= 30) its optical depth is the asymptotic series
+//   tau_l(x) = sum_{m<6} K_m x^-(2m+2),   x = A g - B  linear in g = 1/wave,
+// a function so smooth over a block of 192 pixels that a short polynomial in t = (g - g_c)/hw, |t| <= 1, carries it:
+// with x = x_c (1 + r t), r = A hw / x_c,
+//   x^-k = x_c^-k sum_j (-1)^j C(k+j-1, j) r^j t^j .
+// farfield_kernel adds the first FF_NC coefficients of every line that is far enough from the block (|r| <= 1/8, and
+// the neglected tail K_0 x_c^-2 13 |r|^12 / (1-|r|)^2 below 1e-16 in optical depth) into ONE polynomial per (walker,
+// block) and records which lines it covers; the tile kernel's FF instance then pays FF_NC FMAs per pixel for ALL
+// those lines together and walks only the others (C2: 19 lines, of which 15-19 are far from most blocks).  Members of
+// a multipole cluster go in together or not at all, so that the cluster's own expansion never counts a line twice.
+constexpr int FF_NC = 12, FF_STRIDE = 16, FF_MASK0 = 12;      // per (walker, block): c_0..c_11 | 2 mask words | pad
+constexpr int FF_M = 6;
+struct FFTable { double b[FF_M][FF_NC]; };
+constexpr FFTable make_ff_table() {
+    FFTable t{};
+    for (int m = 0; m < FF_M; ++m) {
+        const int k = 2 * m + 2;
+        double c = 1.0;                                          // C(k+j-1, j), j = 0
+        for (int j = 0; j < FF_NC; ++j) {
+            t.b[m][j] = (j & 1) ? -c : c;
+            c = c * (double)(k + j) / (double)(j + 1);           // -> C(k+j, j+1)
+        }
+    }
+    return t;
+}
+__device__ const FFTable g_ff = make_ff_table();
+
+// (-1)^i C(k+i-1, i) for the powers k = 2 .. FF_KMAX+1 of a cluster's multipole series
+constexpr int FF_KMAX = MP_J0;              // cluster expansions: every tier of the multipole series (5 ... 26 terms)
+struct FFTable2 { double b[FF_KMAX][FF_NC]; };
+constexpr FFTable2 make_ff_table2() {
+    FFTable2 t{};
+    for (int jq = 0; jq < FF_KMAX; ++jq) {
+        const int k = jq + 2;
+        double c = 1.0;
+        for (int i = 0; i < FF_NC; ++i) {
+            t.b[jq][i] = (i & 1) ? -c : c;
+            c = c * (double)(k + i) / (double)(i + 1);
+        }
+    }
+    return t;
+}
+__device__ const FFTable2 g_ff2 = make_ff_table2();
+
+// sum_{jq < J} p_jq (1 + r t)^-(jq+2) -> coefficients of t^i, added to c (J wave-uniform; a lane with fewer terms holds zeros)
+template <int J>
+__device__ __forceinline__ void ff_cluster_accum(const double (&pq)[FF_KMAX], double r, double (&c)[FF_NC]) {
+    double ri = 1.0;
+#pragma unroll
+    for (int i = 0; i < FF_NC; ++i) {
+        double inner = pq[J - 1] * g_ff2.b[J - 1][i];
+#pragma unroll
+        for (int jq = J - 2; jq >= 0; --jq) inner = __builtin_fma(pq[jq], g_ff2.b[jq][i], inner);
+        c[i] = __builtin_fma(inner, ri, c[i]);
+        ri *= r;
+    }
+}
+
+__global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, const double* __restrict__ lc, int W) {
+    // one wave = 64 blocks of ONE walker (grid.y): the walker's records, the cluster tables and all the bookkeeping on
+    // them are wave-uniform (scalar loads, scalar ALU); per lane only the block's own numbers
+    const int nb = I.ntiles * I.ff_nblk;
+    const int w = blockIdx.y;
+    const int b = min((int)(blockIdx.x * 64 + threadIdx.x), nb - 1);
+    const bool store = (int)(blockIdx.x * 64 + threadIdx.x) < nb;     // (lanes past the end repeat the last block)
+    const long idx = (long)w * nb + b;
+    double* __restrict__ out = I.ff + (size_t)idx * FF_STRIDE;
+    const double gc = I.ff_tab[4 * b], hw = I.ff_tab[4 * b + 1];
+    rec_t recs = as_rec(lc + (size_t)w * (T.L + T.NCm) * LC_STRIDE);      // (written by the launch before: scalar loads)
+    double c[FF_NC];
+#pragma unroll
+    for (int j = 0; j < FF_NC; ++j) c[j] = 0.0;
+    unsigned long long mask[2] = {0ull, 0ull}, member[2] = {0ull, 0ull};
+    const bool live = hw >= 0.0 && T.L <= 128;                  // (hw < 0: the block holds no pixel)
+    // ---- clusters: the multipole series of the whole cluster, where the block lies in one of its far tiers; its
+    //      member lines are then covered together (and never one by one: the cluster's own expansion in the tile
+    //      kernel must not count a line twice)
+    for (int k = 0; k < T.NCm; ++k) {
+        const int first = T.cl_first[k], n = T.cl_count[k];
+        unsigned long long rm[2] = {0ull, 0ull};                 // the members' bits (wave-uniform)
+        for (int l = first; l < first + n; ++l) rm[l >> 6] |= 1ull << (l & 63);
+        member[0] |= rm[0]; member[1] |= rm[1];
+        rec_t mrec = recs + (size_t)(T.L + k) * LC_STRIDE;
+        // everything the item may need in ONE batch of scalar loads (its address does not wait for the tables above):
+        // the launch is a chain of load round trips, one per item this way instead of three
+        double Qk[FF_KMAX];
+#pragma unroll
+        for (int jq = 0; jq < FF_KMAX; ++jq) Qk[jq] = mrec[MP_Q0 + jq];
+        const double Ac = mrec[MP_A], Bc = mrec[MP_B];
+        const double yc = __builtin_fma(Ac, gc, -Bc), ayc = fabs(yc), hwy = fabs(Ac) * hw, ynear = ayc - hwy;
+        int J = ynear >= mrec[MP_Y0 + 4] ? MP_J4 : (ynear >= mrec[MP_Y0 + 3] ? MP_J3 : (ynear >= mrec[MP_Y0 + 2] ? MP_J2 :
+                (ynear >= mrec[MP_Y0 + 1] ? MP_J1 : (ynear >= mrec[MP_Y0] ? MP_J0 : 0))));
+        bool ok = live && J > 0 && hwy <= 0.125 * ayc;
+        const double iyc = fast_rcp(yc);
+        if (ok) {
+            const double rho = hwy * fabs(iyc), r2 = rho * rho, r4 = r2 * r2, r12 = r4 * r4 * r4, om = 1.0 - rho;
+            ok = fabs(Qk[0]) * (iyc * iyc) * 13.0 * r12 <= 1e-16 * (om * om);
+        }
+        if (!ok) J = 0;
+        const bool j26 = __ballot(J > MP_J1) != 0ull, j15 = __ballot(J > MP_J2) != 0ull;
+        const bool j10 = __ballot(J > MP_J3) != 0ull, j7 = __ballot(J > MP_J4) != 0ull, j5 = __ballot(J > 0) != 0ull;
+        if (j5) {
+            double pq[FF_KMAX], ip = iyc * iyc;
+#pragma unroll
+            for (int jq = 0; jq < FF_KMAX; ++jq) { pq[jq] = jq < J ? Qk[jq] * ip : 0.0; ip *= iyc; }
+            const double r = (Ac * hw) * iyc;
+            if (j26) ff_cluster_accum<MP_J0>(pq, r, c);
+            else if (j15) ff_cluster_accum<MP_J1>(pq, r, c);
+            else if (j10) ff_cluster_accum<MP_J2>(pq, r, c);
+            else if (j7) ff_cluster_accum<MP_J3>(pq, r, c);
+            else ff_cluster_accum<MP_J4>(pq, r, c);
+            if (J > 0) { mask[0] |= rm[0]; mask[1] |= rm[1]; }
+        }
+    }
+    // ---- the other lines one by one
+    for (int l = 0; l < T.L; ++l) {
+        if ((member[l >> 6] >> (l & 63)) & 1ull) continue;
+        rec_t rec = recs + (size_t)l * LC_STRIDE;
+        double Kl[FF_M];
+#pragma unroll
+        for (int mm = 0; mm < FF_M; ++mm) Kl[mm] = rec[LC_K0 + mm];
+        const double A = rec[LC_A], B = rec[LC_B], K0 = Kl[0];
+        const int mode = rec_int(rec, LC_MODE, 0);
+        const double xc = __builtin_fma(A, gc, -B), axc = fabs(xc), hwx = fabs(A) * hw;
+        bool ok = live && mode == 0 && (axc - hwx >= 30.0) && (hwx <= 0.125 * axc);
+        const double ixc = fast_rcp(xc), sc = ixc * ixc;
+        if (ok) {
+            const double rho = hwx * fabs(ixc), r2 = rho * rho, r4 = r2 * r2, r12 = r4 * r4 * r4, om = 1.0 - rho;
+            ok = fabs(K0) * sc * 13.0 * r12 <= 1e-16 * (om * om);      // (NaN: not ok)
+        }
+        if (__ballot(ok) == 0ull) continue;
+        double q[FF_M], sp = sc;
+#pragma unroll
+        for (int mm = 0; mm < FF_M; ++mm) { q[mm] = ok ? Kl[mm] * sp : 0.0; sp *= sc; }
+        const double r = ok ? (A * hw) * ixc : 0.0;
+        double rj = 1.0;
+#pragma unroll
+        for (int j = 0; j < FF_NC; ++j) {
+            double inner = q[FF_M - 1] * g_ff.b[FF_M - 1][j];
+#pragma unroll
+            for (int mm = FF_M - 2; mm >= 0; --mm) inner = __builtin_fma(q[mm], g_ff.b[mm][j], inner);
+            c[j] = __builtin_fma(inner, rj, c[j]);
+            rj *= r;
+        }
+        if (ok) mask[l >> 6] |= 1ull << (l & 63);
+    }
+    if (!store) return;
+#pragma unroll
+    for (int j = 0; j < FF_NC; ++j) out[j] = c[j];
+    reinterpret_cast<unsigned long long*>(out)[FF_MASK0] = mask[0];
+    reinterpret_cast<unsigned long long*>(out)[FF_MASK0 + 1] = mask[1];
+}
+
+// ---------------------------------------------------------------------------------------------
 // tile work
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_THREADS_MAX = 256;   // tile_kernel: 1, 2 or 4 waves per workgroup
@@ -422,6 +584,9 @@ __device__ long long g_stamps[STAMP_W * STAMP_WAVES * STAMP_STAGES];
 #define VP_STAMP_ARG
 #define VP_STAMP_PASS
 #define VP_STAMP_NONE
+#endif
+#ifndef VP_TILE_WPE
+#define VP_TILE_WPE 1             // tile_kernel: waves per SIMD the register allocation must leave room for
 #endif
 #ifndef VP_CORE_ILP
 #define VP_CORE_ILP 2             // phase B of single-wave tiles in walker_kernel: flagged chunks evaluated side by side
@@ -700,6 +865,15 @@ __device__ __forceinline__ void lsf_block(const InstDev& I, const double* __rest
     }
 }
 
+// FF: the first line >= `from` of the 64-line word [l0, l1) whose bit in `nearm` is set (not covered by the block's
+// far-field expansion), or l1.
+__device__ __forceinline__ int next_near_line(unsigned long long nearm, int from, int l0, int l1) {
+    const int k = from - l0;
+    if (k >= 64) return l1;
+    const unsigned long long m = nearm >> k;
+    return m ? min(l1, from + (int)__builtin_ctzll(m)) : l1;
+}
+
 // One tile of one walker -- output pixels [p0, p0 + nout) -- : tau -> exp -> LSF -> chi^2 (OUT = 0; returns this
 // LANE's sum of chi^2 terms) or model flux written to `out` (OUT = 1 convolved, 2 unconvolved).  `first` (uniform):
 // the LDS tables (taps, exp table) are staged; a wave that works through several tiles in a row passes false from
@@ -710,13 +884,15 @@ __device__ __forceinline__ void lsf_block(const InstDev& I, const double* __rest
 //   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | exp table | per-chunk "line core" masks
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
 // fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
-template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false>
+template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false, bool FF = false>
 __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
                                             int tid, int nthreads, const TilePre& pre, bool first,
-                                            double* __restrict__ out, int out_stride VP_STAMP_ARG, bool daw_ready = false) {
+                                            double* __restrict__ out, int out_stride VP_STAMP_ARG, bool daw_ready = false,
+                                            int tix = 0) {
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
-    const int lane = SOLO ? tid : (tid & 63), wid = SOLO ? 0 : (tid >> 6);     // SOLO: tid IS the lane
+    const int lane = SOLO ? tid : (tid & 63);                                  // SOLO: tid IS the lane
+    const int wid = SOLO ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, and the compiler knows it
     const int TILE_THREADS = SOLO ? 64 : nthreads, nwaves = SOLO ? 1 : (nthreads >> 6);
     double* __restrict__ daw = fl + I.span + FL_PAD + 4;   // Dawson table for the line cores (16-B aligned)
     const int Kp = (I.K + 7) & ~7;                     // taps are zero-padded to whole groups of 8 (in HBM, host side)
@@ -751,14 +927,26 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
         bool pending[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) pending[r] = false;
+        // FF: this pass's block of the walker's far-field expansions (tile tix, block base / (64 RB))
+        const int fblk = FF ? tix * I.ff_nblk + base / (64 * RB) : 0;
+        rec_t ffr = FF ? as_rec(I.ff + ((size_t)w * (I.ntiles * I.ff_nblk) + fblk) * FF_STRIDE) : (rec_t)0;
         if (METHOD == 0) {
             for (int l0 = 0; l0 < I.L; l0 += 64) {
                 unsigned long long todo[RB];
 #pragma unroll
                 for (int r = 0; r < RB; ++r) todo[r] = 0ull;
                 const int l1 = min(I.L, l0 + 64);
-                Eager nxt = load_eager<SOLO>(lcw + (size_t)l0 * LC_STRIDE);
-                for (int l = l0; l < l1; ++l) {
+                // FF: the lines of this word that the block's expansion covers are not walked at all
+                unsigned long long nearm = ~0ull;
+                if (FF) {
+                    const unsigned int flo = (unsigned int)rec_int(ffr, FF_MASK0 + (l0 >> 6), 0);
+                    const unsigned int fhi = (unsigned int)rec_int(ffr, FF_MASK0 + (l0 >> 6), 1);
+                    nearm = ~(((unsigned long long)fhi << 32) | (unsigned long long)flo);
+                }
+#define VP_NEXT_LINE(from) (FF ? next_near_line(nearm, (from), l0, l1) : (from))
+                const int lfirst = VP_NEXT_LINE(l0);
+                Eager nxt = load_eager<SOLO>(lcw + (size_t)min(lfirst, I.L - 1) * LC_STRIDE);
+                for (int l = lfirst; l < l1; l = VP_NEXT_LINE(l + 1)) {
                     // far from a whole cluster of components?  one multipole evaluation replaces all of
                     // its member lines (only tried at the first line of a cluster that fits this block)
                     const int mp = (I.line_sel < 0) ? nxt.mp : -1;
@@ -792,18 +980,18 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                                 multipole_rb<MP_J0>(y, mrec + MP_Q0, tau);
                             }
                             l = max(l, nxt.cl_end - 1);                // skip the member lines (never backwards, whatever a record holds)
-                            nxt = load_eager<SOLO>(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
+                            nxt = load_eager<SOLO>(lcw + (size_t)min(VP_NEXT_LINE(l + 1), I.L - 1) * LC_STRIDE);
                             continue;
                         }
                     }
                     const Eager cur = nxt;
                     if (SOLO) asm volatile("" :: "s"(cur.touch1), "s"(cur.touch2));
                     if (I.line_sel >= 0 && l != I.line_sel) {
-                        nxt = load_eager<SOLO>(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);
+                        nxt = load_eager<SOLO>(lcw + (size_t)min(VP_NEXT_LINE(l + 1), I.L - 1) * LC_STRIDE);
                         continue;
                     }
                     rec_t rec = lcw + (size_t)l * LC_STRIDE;
-                    nxt = load_eager<SOLO>(lcw + (size_t)min(l + 1, I.L - 1) * LC_STRIDE);   // scalar prefetch of the next line
+                    nxt = load_eager<SOLO>(lcw + (size_t)min(VP_NEXT_LINE(l + 1), I.L - 1) * LC_STRIDE);   // scalar prefetch of the next line
                     const unsigned long long bit = 1ull << (l - l0);
                     const double A = cur.A, B = cur.B;
                     rec_t K = rec + LC_K0;
@@ -848,6 +1036,23 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                     const int c = (base >> 6) + r;
                     if (lane == 0 && c < nchunks) cmask[c * nwords + (l0 >> 6)] = todo[r];
                 }
+            }
+#undef VP_NEXT_LINE
+            if (FF) {      // all the far lines of this block at once: FF_NC FMAs per pixel
+                rec_t tb = as_rec(I.ff_tab) + 4 * fblk;
+                const double ihw = tb[2], gci = tb[3];
+                double t[RB], pa[RB];
+                const double ctop = ffr[FF_NC - 1];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) { t[r] = __builtin_fma(g[r], ihw, -gci); pa[r] = ctop; }
+#pragma unroll
+                for (int j = FF_NC - 2; j >= 0; --j) {
+                    const double cj = ffr[j];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) pa[r] = __builtin_fma(pa[r], t[r], cj);
+                }
+#pragma unroll
+                for (int r = 0; r < RB; ++r) tau[r] += pa[r];
             }
         } else if (METHOD == 1) {
             for (int l = 0; l < I.L; ++l) {
@@ -1015,8 +1220,9 @@ __device__ __forceinline__ void publish_partial(const FinalizeArgs& F, double* _
 // Tile kernel: grid (W, tiles) x 64/128/256 threads, workgroup = walker x pixel tile; records come from a
 // prep_lines_kernel launch.  GENERIC = false skips walkers flagged in `genflag`, GENERIC = true processes
 // ONLY the flagged walkers: every (walker, tile) is handled by exactly one of the two launches.
-template <int METHOD, int OUT, bool GENERIC>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
-__global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const double* __restrict__ lc,
+template <int METHOD, int OUT, bool GENERIC, bool FF = false>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
+                                                                // FF: far lines come from the block's expansion (farfield_kernel)
+__global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(InstDev I, const double* __restrict__ lc,
                                                             const int* __restrict__ flags,
                                                             double* __restrict__ out, int out_stride,
                                                             int out_offset, FinalizeArgs F,
@@ -1039,8 +1245,8 @@ __global__ __launch_bounds__(TILE_THREADS_MAX) void tile_kernel(InstDev I, const
                                                out + (size_t)blockIdx.z * I.P, out_stride VP_STAMP_NONE);
         return;
     }
-    const double wsum = wave_sum(tile_work<METHOD, OUT, GENERIC, false>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x, pre, true,
-                                                                        out, out_stride VP_STAMP_NONE));
+    const double wsum = wave_sum(tile_work<METHOD, OUT, GENERIC, false, true, false, FF>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x,
+                                                                                         pre, true, out, out_stride VP_STAMP_NONE, false, t));
     if (OUT == 0) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
         double* red = fl + I.span + FL_PAD;
@@ -1294,7 +1500,15 @@ __global__ __launch_bounds__(64) void finalize_kernel(double* __restrict__ parti
     for (int k = 0; k < n_inst; ++k) {
         const int t0 = BYVALUE ? V.tile_off[k] : F.tile_off[k], t1 = BYVALUE ? V.tile_off[k + 1] : F.tile_off[k + 1];
         double sk = 0.0;
-        for (int tt = t0; tt < t1; ++tt) sk += row[tt];
+        int tt = t0;
+        for (; tt + 8 <= t1; tt += 8) {        // eight loads in flight (one 64-byte line of the walker's row), added in tile
+            double v[8];                       // order: with 182 tiles (C4) the one-load-at-a-time loop was a 34 us chain
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[tt + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sk += v[u];
+        }
+        for (; tt < t1; ++tt) sk += row[tt];
         total += -0.5 * (sk - (BYVALUE ? V.sum_logw[k] : F.sum_logw[k]));   // vfit_mcmc.py:309-311
     }
     if (oob) return;                                  // out-of-bounds walkers keep the -inf written by prep

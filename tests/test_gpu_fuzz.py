@@ -90,7 +90,10 @@ def test_random_configuration(seed):
         un = e.model_flux(0, thetas[:2], convolved=False)
     np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     np.testing.assert_allclose(got_big, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
-    np.testing.assert_array_equal(got_walker, got_big)     # same tiles, same summation order: bit-identical
+    if data.n_lines < 8:
+        np.testing.assert_array_equal(got_walker, got_big)     # same tiles, same summation order: bit-identical
+    else:       # the tile launches take far lines from per-block expansions from 8 lines on, the walker kernel does not
+        np.testing.assert_allclose(got_walker, got_big, rtol=1e-13, atol=1e-10)
     for i in range(3):
         np.testing.assert_allclose(fl[i], vo.model_flux(od, thetas[i], wave), rtol=0, atol=FLUX_ATOL)
     for i in range(2):
@@ -173,3 +176,54 @@ def test_instruments_sharing_or_not_sharing_their_line_tables():
             got_big = e.lnprob(thetas)
         np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL, err_msg=str(order))
         np.testing.assert_allclose(got_big, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL, err_msg=str(order))
+
+
+@pytest.mark.parametrize("seed", [3, 11, 29])
+def test_farfield_expansions_agree_with_direct_evaluation(seed):
+    """From 8 lines on, the tile launches take the lines that are far from a block of 192 pixels from ONE polynomial per
+    (walker, block) instead of walking them (farfield_kernel).  Same spectrum with the expansions on and off, and the
+    oracle: many lines, a damped component (must stay out of the expansions until it is far enough), wide and narrow
+    grids, ascending and descending."""
+    import rbvfit_amd
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    rng = np.random.default_rng(seed)
+    cfg = FitConfiguration()
+    cfg.add_system(0.348, "MgII", [2796.352, 2803.531], 3)
+    cfg.add_system(0.3485, "FeII", [2600.1729, 2586.650, 2382.765], 3)
+    cfg.add_system(0.90, "CIV", [1548.195, 1550.770], 2)
+    cfg.add_system(2.05, "HI", [1215.6701], 1)
+    C = cfg.total_components
+    model = VoigtModel(cfg, FWHM="6.5")
+    data = model.compile().data
+    assert data.n_lines >= 8
+    lo, hi, P = [(2900.0, 3800.0, 9000), (3650.0, 3800.0, 6000), (3000.0, 3790.0, 3000)][seed % 3]
+    wave = np.linspace(lo, hi, P)
+    if seed % 2:
+        wave = wave[::-1].copy()
+    N = rng.uniform(12.5, 14.5, C); N[-1] = rng.uniform(19.0, 20.3)        # the HI component is damped
+    theta = np.concatenate([N, rng.uniform(6, 40, C), rng.uniform(-150, 150, C)])
+    lb = np.concatenate([np.full(C, 10.0), np.full(C, 1.0), np.full(C, -400.0)])
+    ub = np.concatenate([np.full(C, 21.0), np.full(C, 150.0), np.full(C, 400.0)])
+    thetas = np.clip(theta + rng.standard_normal((5, 3 * C)) * np.concatenate([np.full(C, 0.1), np.full(C, 2.0), np.full(C, 10.0)]),
+                     lb + 1e-9, ub - 1e-9)
+    od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors, data.N_indices,
+                            data.b_indices, data.v_indices, data.taps, data.lsf_mode, data.voigt_method)
+    err = np.full(P, 0.03)
+    flux = vo.model_flux(od, thetas[0], wave) + rng.normal(0, 0.03, P)
+    inst = vo.OracleInstrument.from_error(od, wave, flux, err)
+    ref = vo.lnprob_batch(thetas, lb, ub, [inst])
+    got = {}
+    for ff in (0, 1):
+        with rbvfit_amd.Engine(0) as e:
+            e.set_option("farfield", ff)                      # (read when the instrument is added)
+            e.set_bounds(lb, ub)
+            e.add_instrument(wave, flux, inst.inv_sigma2, inst.log_inv_sigma2, **data.engine_kwargs())
+            e.set_option("walker", 0)
+            a = e.lnprob(thetas)
+            e.set_option("geom", 0); e.set_option("finalize", 0)
+            b = e.lnprob(thetas)
+            got[ff] = (a, b)
+    for k in (0, 1):
+        np.testing.assert_allclose(got[1][k], got[0][k], rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(got[1][k], ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
