@@ -167,13 +167,15 @@ int vp_profile_enable(vp_ctx* ctx, int enable);
 int vp_profile_read(vp_ctx* ctx, double* prep_ms, double* tile_ms, double* finalize_ms,
                     int* n_tile_launches);
 
-/* Tuning / experiment knobs of ONE context (none changes a result beyond the last bit of the chi^2 grouping).
+/* Tuning / experiment knobs of ONE context (none changes a result beyond the last bits: the grouping of the chi^2 sum,
+ * and with "farfield" the far wings of lines that are many block widths away, each to 1e-16 in optical depth).
  * Defaults come from the RBVFIT_AMD_<NAME> environment variables, read once in vp_ctx_create -- never on
  * the per-call path.  Names: "geom" (-1 by batch size, 0 two-pass tiles, 1 one-pass tiles), "finalize"
  * (-1 auto, 0 own launch, 1 ticket), "walker" (-1 by batch size, 0 never, 1 whenever possible: the whole
- * batch as ONE launch, workgroup = walker), "walker_max_waves", "prep_rpw", "zerocopy_max",
- * "no_zerocopy", "no_fused_accept"; "span", "waves", "no_multipole", "lds_pad" apply to instruments added
- * afterwards.  Unknown name -> VP_EINVAL. */
+ * batch as ONE launch, workgroup = walker), "prep_rpw", "zerocopy_max", "no_zerocopy", "no_fused_accept",
+ * "slice_rows"; "span", "waves", "no_multipole", "multipole_min", "lds_pad" and "farfield" (-1: per-block far-field
+ * expansions for instruments with >= 8 lines, 0 never, 1 whenever possible) apply to instruments added afterwards.
+ * Unknown name -> VP_EINVAL. */
 int vp_set_option(vp_ctx* ctx, const char* name, long value);
 
 /* ---- several GPUs from one process (the torch-free, RCCL-free form of the walker sharding) ----
