@@ -339,7 +339,8 @@ def rank_main(args):
         pr = eng.profile_read()
         eng.profile_enable(False)
         kind = eng.last_launch_kind
-        kernel_name = "vp::walker_kernel<0, false>" if kind == "walker" else "vp::tile_kernel<0, 0, false>"
+        kernel_name = {"walker": "vp::walker_kernel<0, false, false>", "tiles+farfield": "vp::tile_kernel<0, 0, false, true>"}.get(
+            kind, "vp::tile_kernel<0, 0, false, false>")
         # Per-launch event pairs put record gaps (and, between dependent kernels, extra serialisation) into every
         # interval -- 8-10 % on a 200-700 us kernel, more on a 30 us one -- so they are only used for the SHARE of the
         # step each kernel kind takes; the step itself is timed by ONE pair of events around nprof back-to-back passes
@@ -383,7 +384,10 @@ def rank_main(args):
         vt = flops / len(wl.pixels) / (tile_ms * 1e-3) / 1e12
         roof["valu_fp64"] = dict(bound="valu_fp64", unit="TFLOP/s", peak=FP64_VALU_PEAK_TFLOPS, achieved=vt,
                                  frac=vt / FP64_VALU_PEAK_TFLOPS, algorithmic_flops_per_eval=wl.algorithmic_flops_per_eval,
-                                 model="per (line,pixel) 8 + (150 if |x|<8 else 12) + 1; per pixel 30 + 2K + 4")
+                                 model="per (line,pixel) 8 + (150 if |x|<8 else 12) + 1; per pixel 30 + 2K + 4",
+                                 note="ALGORITHMIC flops: every (line, pixel) pair counted as the reference evaluates it; the "
+                                      "multipole and far-field expansions execute far fewer (profiles/*_pmc.json has the "
+                                      "instruction counts), so this is a throughput statement, not VALU utilisation")
         host_rate = host_lat = sampler_steps = slice_info = None
         if not args.no_extras:
             # measured device copy bandwidth next to the vendor peak (read + write of a 1 GiB buffer)

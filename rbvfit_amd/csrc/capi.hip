@@ -394,6 +394,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         const vp::InstDev& geom = sel ? in.dev_s : in.dev;
         double* ff = (in.ff_on && c->d_ff) ? c->d_ff : nullptr;
         if (ff) {                                        // the blocks' far-field expansions from the records just made
+            c->last_kind = 2;
             vp::InstDev g2 = geom;
             g2.ff = ff;
             const int nbk = geom.ntiles * geom.ff_nblk;

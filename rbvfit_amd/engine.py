@@ -270,10 +270,11 @@ class Engine:
 
     @property
     def last_launch_kind(self) -> str:
-        """'walker' when the last lnprob batch ran as ONE walker_kernel launch, else 'tiles' (prep + tile
-        (+ finalize) launches)."""
+        """'walker' when the last lnprob batch ran as ONE walker_kernel launch, 'tiles' for prep + tile (+ finalize)
+        launches, 'tiles+farfield' when those took far lines from per-block expansions (farfield_kernel)."""
         self._guard()
-        return "walker" if self._lib.vp_last_launch_kind(self._ctx) == 1 else "tiles"
+        kind = self._lib.vp_last_launch_kind(self._ctx)
+        return "walker" if kind == 1 else ("tiles+farfield" if kind == 2 else "tiles")
 
     # -- per-kernel timing (HIP events on the launch stream) ------------------------------------
     def profile_enable(self, on: bool = True):

@@ -221,6 +221,7 @@ def test_farfield_expansions_agree_with_direct_evaluation(seed):
             e.add_instrument(wave, flux, inst.inv_sigma2, inst.log_inv_sigma2, **data.engine_kwargs())
             e.set_option("walker", 0)
             a = e.lnprob(thetas)
+            assert e.last_launch_kind == ("tiles+farfield" if ff else "tiles")
             e.set_option("geom", 0); e.set_option("finalize", 0)
             b = e.lnprob(thetas)
             got[ff] = (a, b)
