@@ -308,3 +308,25 @@ def test_slice_sampler_rejects_nan_and_bad_shapes():
     s = EnsembleSliceSampler(8, 2, lambda x: np.full(len(x), -np.inf), seed=0)
     with pytest.raises(ValueError, match="finite"):
         s.run_mcmc(np.zeros((8, 2)), 1)
+
+
+def test_farfield_expansion_series_and_tail_bound():
+    """The arithmetic farfield_kernel relies on (csrc/voigt_kernels.h), checked in exact-enough NumPy: with
+    x = x_c (1 + r t), |t| <= 1,   x^-k = x_c^-k sum_j (-1)^j C(k+j-1, j) r^j t^j,   and the first 12 terms of the k = 2
+    series miss the full value by less than 13 |r|^12 / (1 - |r|)^2 (relative); higher k only as weights of x_c^-(k-2)."""
+    from math import comb
+    t = np.linspace(-1.0, 1.0, 401)
+    for r in (0.125, -0.125, 0.06, -0.01):
+        for k in (2, 4, 6, 12):
+            full = (1.0 + r * t) ** (-k)
+            part = sum((-1) ** j * comb(k + j - 1, j) * r ** j * t ** j for j in range(12))
+            err = np.max(np.abs(part - full) / full)
+            if k == 2:
+                assert err <= 13.0 * abs(r) ** 12 / (1.0 - abs(r)) ** 2 + 1e-15, (r, k, err)
+            # the terms of a line are K_m x_c^-(2m+2): against the k = 2 term the k-th one is down by x_c^-(k-2) <= 30^-(k-2),
+            # which outweighs the faster growth of its coefficients
+            assert err * 30.0 ** (-(k - 2)) <= 13.0 * 0.125 ** 12 / 0.875 ** 2 * 1.0001 + 1e-15, (r, k, err)
+    # the kernel's acceptance rule keeps K_0 x_c^-2 * bound below 1e-16 in optical depth: at the widest allowed block
+    # (|r| = 1/8) that admits lines whose optical depth at the block is below ~4e-7
+    bound = 13.0 * 0.125 ** 12 / 0.875 ** 2
+    assert 3e-7 < 1e-16 / bound < 5e-7
