@@ -38,7 +38,7 @@ struct Tuning {
     long lds_pad = 0;           // extra LDS bytes per tile workgroup: occupancy experiments
     int no_fused_accept = 0;    // device sampler: separate accept / propose launches
     int farfield = -1;          // far-field expansions in the tile launches: -1 for instruments with >= 8 lines and batches
-                                // with walkers x blocks x lines >= 1e6, 0 never, 1 whenever possible (the instrument's
+                                // with walkers x blocks x lines >= 4e5, 0 never, 1 whenever possible (the instrument's
                                 // block tables are made when it is added: 0 at that time rules them out for good)
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
@@ -393,9 +393,10 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr, s);
         }
         const vp::InstDev& geom = sel ? in.dev_s : in.dev;
-        // (the extra launch costs ~20 us; what it saves grows with walkers x blocks x lines: C2 = 1.7e6 saves 60 us.
-        // Below ~1e6 the lines are walked directly unless "farfield" = 1 asks for the expansions whenever possible)
-        const bool ff_pays = c->tune.farfield > 0 || (long)W * geom.ntiles * geom.ff_nblk * in.dev.L >= 1000000l;
+        // (the extra launch costs ~20 us; what it saves grows with walkers x blocks x lines -- measured on C2, us per pass
+        // without / with: 128 walkers 54.8 / 60.5, 256 (0.42e6): 72.7 / 71.5, 512: 111.8 / 98.3, 1024: 188.8 / 153.1,
+        // 2048: 349.0 / 260.5.  Below 4e5 the lines are walked directly unless "farfield" = 1 asks for the expansions)
+        const bool ff_pays = c->tune.farfield > 0 || (long)W * geom.ntiles * geom.ff_nblk * in.dev.L >= 400000l;
         double* ff = (in.ff_on && c->d_ff && ff_pays) ? c->d_ff : nullptr;
         if (ff) {                                        // the blocks' far-field expansions from the records just made
             c->last_kind = 2;
