@@ -40,6 +40,9 @@ struct Tuning {
     int farfield = -1;          // far-field expansions in the tile launches: -1 for instruments with >= 8 lines and batches
                                 // with walkers x blocks x lines >= 4e5, 0 never, 1 whenever possible (the instrument's
                                 // block tables are made when it is added: 0 at that time rules them out for good)
+    int walker_clusters = 0;    // walker_kernel on instruments with multipole clusters: 0 = walk the member lines one by one
+                                // (no cluster records: the plain instance), 1 = cluster records formed in the workgroup
+                                // (that instance spills to scratch)
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
 
@@ -51,7 +54,7 @@ const Knob g_knobs[] = {
     VP_KNOB(zerocopy_max, "RBVFIT_AMD_ZEROCOPY_MAX", 1),
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
-    VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0),
+    VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
@@ -312,9 +315,16 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
 // walker kernel / prep + tile + finalize launches) 64: 18.2 / 22.3, 128: 18.3 / 23.5, 256: 18.3 / 24.9,
 // 320: 24.8 / 26.9, 384: 24.8 / 29.3, 512: 25.0 / 31.0, 640: 38.5 / 35.5, 768: 38.9 / 36.4, 1024: 47.3 / 43.1.
 // By default it is therefore used whenever the batch fits the CUs at once (at most two layers); larger batches keep
-// the one-wave workgroups, whose slots the hardware refills one by one as tiles finish.
+// the one-wave workgroups, whose slots the hardware refills one by one as tiles finish.  Instruments with multipole
+// clusters (>= 3 components of a transition) run it WITHOUT cluster records, their members as ordinary lines: forming
+// the records in the workgroup costs a long per-lane chain and scratch; measured on 4096 pixels, us per pass, walker
+// kernel / launches: MgII doublet x 3 components 256 walkers 22.5 / 32.1, 512: 29.3 / 39.2; x 4: 28.5 / 36.5 and
+// 38.6 / 49.1; FeII 4 transitions x 4: 32.2 / 38.2 and 43.7 / 51.8.
 size_t walker_lds_bytes(const Instrument& in) { return (size_t)in.dev.ntiles * in.lds_bytes + (in.dev.ntiles + 2) * sizeof(double); }
 
+#ifndef VP_WALKER_MAX_CLUSTER_LINES
+#define VP_WALKER_MAX_CLUSTER_LINES 64
+#endif
 bool walker_applies(const vp_ctx* c, int W) {
     if (c->tune.walker == 0 || c->inst.size() != 1) return false;
     const Instrument& in = c->inst[0];
@@ -322,7 +332,7 @@ bool walker_applies(const vp_ctx* c, int W) {
     if (in.dev.method == VP_VOIGT_WOFZ && in.needs_generic) return false;
     if (walker_lds_bytes(in) > c->lds_limit) return false;
     if (c->tune.walker == 1) return true;
-    if (in.dev.NCm > 0) return false;                     // (the cluster-record instance spills to scratch: launches are faster)
+    if (in.dev.NCm > 0 && (c->tune.walker_clusters || in.dev.L > VP_WALKER_MAX_CLUSTER_LINES)) return false;
     // a CU holds per_cu walker workgroups at once (24 wave slots / waves per walker, LDS permitting); the batch lies
     // on the 256 CUs in layers of 256 workgroups and the launch takes as long as the fullest CU's layers
     const int per_cu = std::max(1, std::min(24 / std::max(1, in.dev.ntiles), (int)(c->lds_limit / walker_lds_bytes(in))));
@@ -337,8 +347,14 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     const dim3 grid(W), block(64 * in.dev.ntiles);
     const size_t lds = walker_lds_bytes(in);
     if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, false>), grid, block, lds, s, in.dev, in.lines, a, none);
-    else if (in.dev.NCm > 0) hipLaunchKernelGGL((vp::walker_kernel<0, true, false>), grid, block, lds, s, in.dev, in.lines, a, none);
-    else hipLaunchKernelGGL((vp::walker_kernel<0, false, false>), grid, block, lds, s, in.dev, in.lines, a, none);
+    else if (in.dev.NCm > 0 && c->tune.walker_clusters) hipLaunchKernelGGL((vp::walker_kernel<0, true, false>), grid, block, lds, s, in.dev, in.lines, a, none);
+    else {
+        // (clusters: without their multipole records the members are ordinary lines -- a few more wing evaluations
+        // per pass against a cluster preparation chain inside every workgroup)
+        vp::InstDev d2 = in.dev; d2.NCm = 0;
+        vp::LinesDev t2 = in.lines; t2.NCm = 0;
+        hipLaunchKernelGGL((vp::walker_kernel<0, false, false>), grid, block, lds, s, d2, t2, a, none);
+    }
 }
 
 // One stretch-move half-step of the active half (nS walkers) as ONE launch: proposal, lnprob and accept/reject inside
@@ -349,7 +365,11 @@ void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStre
     const dim3 grid(nS), block(64 * in.dev.ntiles);
     const size_t lds = walker_lds_bytes(in);
     if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, true>), grid, block, lds, s, in.dev, in.lines, a, st);
-    else hipLaunchKernelGGL((vp::walker_kernel<0, false, true>), grid, block, lds, s, in.dev, in.lines, a, st);
+    else {
+        vp::InstDev d2 = in.dev; d2.NCm = 0;
+        vp::LinesDev t2 = in.lines; t2.NCm = 0;
+        hipLaunchKernelGGL((vp::walker_kernel<0, false, true>), grid, block, lds, s, d2, t2, a, st);
+    }
 }
 
 int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
@@ -913,7 +933,8 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     const int thr = 64;
     // whole half-step in one launch (proposal, lnprob, accept inside each walker's workgroup) where the walker kernel
     // applies to a half-ensemble batch and the instrument has no cluster records
-    const bool one_launch = !c->tune.no_fused_accept && c->tune.walker != 0 && walker_applies(c, half) && c->inst[0].dev.NCm == 0;
+    const bool one_launch = !c->tune.no_fused_accept && c->tune.walker != 0 && walker_applies(c, half) &&
+                            (c->inst[0].dev.NCm == 0 || !c->tune.walker_clusters);
     const bool fuse = W <= 1024 && !c->tune.no_fused_accept;   // accept + next proposal in one launch
     const int wthr = ((W + 63) / 64) * 64;
     bool have_prop = false;                                   // is the proposal of the coming pass already enqueued?

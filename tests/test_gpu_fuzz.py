@@ -90,10 +90,12 @@ def test_random_configuration(seed):
         un = e.model_flux(0, thetas[:2], convolved=False)
     np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     np.testing.assert_allclose(got_big, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
-    if data.n_lines < 8:
+    clustered = any(g.components >= 3 for s in model.config.systems for g in s.ion_groups)
+    if data.n_lines < 8 and not clustered:
         np.testing.assert_array_equal(got_walker, got_big)     # same tiles, same summation order: bit-identical
-    else:       # the tile launches take far lines from per-block expansions from 8 lines on, the walker kernel does not
-        np.testing.assert_allclose(got_walker, got_big, rtol=1e-13, atol=1e-10)
+    else:       # the tile launches use multipole expansions of clusters (>= 3 components of a transition) and, from 8 lines
+                # on, per-block far-field expansions; the walker kernel walks every line
+        np.testing.assert_allclose(got_walker, got_big, rtol=1e-12, atol=1e-9)
     for i in range(3):
         np.testing.assert_allclose(fl[i], vo.model_flux(od, thetas[i], wave), rtol=0, atol=FLUX_ATOL)
     for i in range(2):
