@@ -320,56 +320,79 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
 // the records in the workgroup costs a long per-lane chain and scratch; measured on 4096 pixels, us per pass, walker
 // kernel / launches: MgII doublet x 3 components 256 walkers 22.5 / 32.1, 512: 29.3 / 39.2; x 4: 28.5 / 36.5 and
 // 38.6 / 49.1; FeII 4 transitions x 4: 32.2 / 38.2 and 43.7 / 51.8.
-size_t walker_lds_bytes(const Instrument& in) { return (size_t)in.dev.ntiles * in.lds_bytes + (in.dev.ntiles + 2) * sizeof(double); }
+// (one or two instruments: a second one must have the first one's line tables -- the walker's records serve both)
+int walker_tiles(const vp_ctx* c) {
+    int n = 0;
+    for (auto& in : c->inst) n += in.dev.ntiles;
+    return n;
+}
+size_t walker_wave_lds(const vp_ctx* c) {
+    size_t b = 0;
+    for (auto& in : c->inst) b = std::max(b, in.lds_bytes);
+    return b;
+}
+size_t walker_lds_bytes(const vp_ctx* c) {           // tiles | tile sums, prior flag, spare
+    return (size_t)walker_tiles(c) * walker_wave_lds(c) + (walker_tiles(c) + 2) * sizeof(double);
+}
 
 #ifndef VP_WALKER_MAX_CLUSTER_LINES
 #define VP_WALKER_MAX_CLUSTER_LINES 64
 #endif
 bool walker_applies(const vp_ctx* c, int W) {
-    if (c->tune.walker == 0 || c->inst.size() != 1) return false;
+    if (c->tune.walker == 0 || c->inst.empty() || c->inst.size() > 2 || c->D > 64) return false;
     const Instrument& in = c->inst[0];
-    if (in.nwaves != 1 || in.dev.ntiles > vp::WALKER_THREADS_MAX / 64 || c->D > 64) return false;
-    if (in.dev.method == VP_VOIGT_WOFZ && in.needs_generic) return false;
-    if (walker_lds_bytes(in) > c->lds_limit) return false;
+    for (auto& k : c->inst) {
+        if (k.nwaves != 1 || k.dev.method != in.dev.method) return false;
+        if (k.dev.method == VP_VOIGT_WOFZ && k.needs_generic) return false;
+    }
+    if (c->inst.size() == 2 && (!c->inst[1].same_lines_as_prev || c->tune.walker_clusters)) return false;
+    const int nt = walker_tiles(c);
+    if (nt > vp::WALKER_THREADS_MAX / 64) return false;
+    if (walker_lds_bytes(c) > c->lds_limit) return false;
     if (c->tune.walker == 1) return true;
     if (in.dev.NCm > 0 && (c->tune.walker_clusters || in.dev.L > VP_WALKER_MAX_CLUSTER_LINES)) return false;
     // a CU holds per_cu walker workgroups at once (24 wave slots / waves per walker, LDS permitting); the batch lies
     // on the 256 CUs in layers of 256 workgroups and the launch takes as long as the fullest CU's layers
-    const int per_cu = std::max(1, std::min(24 / std::max(1, in.dev.ntiles), (int)(c->lds_limit / walker_lds_bytes(in))));
+    const int per_cu = std::max(1, std::min(24 / std::max(1, nt), (int)(c->lds_limit / walker_lds_bytes(c))));
     const int layers = (W + 255) / 256;
     return layers <= std::min(per_cu, 2);
 }
 
-void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
+// (clusters: without their multipole records the members are ordinary lines -- a few more wing evaluations per pass
+// against a cluster preparation chain inside every workgroup)
+template <bool SAMPLER>
+void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::StretchArgs& st, hipStream_t s) {
     const Instrument& in = c->inst[0];
-    vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, in.sum_logw, c->D, (int)(in.lds_bytes / sizeof(double))};
-    const vp::StretchArgs none{};
-    const dim3 grid(W), block(64 * in.dev.ntiles);
-    const size_t lds = walker_lds_bytes(in);
-    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, false>), grid, block, lds, s, in.dev, in.lines, a, none);
-    else if (in.dev.NCm > 0 && c->tune.walker_clusters) hipLaunchKernelGGL((vp::walker_kernel<0, true, false>), grid, block, lds, s, in.dev, in.lines, a, none);
-    else {
-        // (clusters: without their multipole records the members are ordinary lines -- a few more wing evaluations
-        // per pass against a cluster preparation chain inside every workgroup)
-        vp::InstDev d2 = in.dev; d2.NCm = 0;
-        vp::LinesDev t2 = in.lines; t2.NCm = 0;
-        hipLaunchKernelGGL((vp::walker_kernel<0, false, false>), grid, block, lds, s, d2, t2, a, none);
+    const dim3 grid(W), block(64 * walker_tiles(c));
+    const size_t lds = walker_lds_bytes(c);
+    vp::InstDev d0 = in.dev;
+    vp::LinesDev t0 = in.lines;
+    const bool keep_clusters = in.dev.NCm > 0 && c->tune.walker_clusters && !SAMPLER && c->inst.size() == 1;
+    if (!keep_clusters) { d0.NCm = 0; t0.NCm = 0; }
+    if (c->inst.size() == 2) {
+        vp::InstDev d1 = c->inst[1].dev;
+        d1.NCm = 0;
+        if (in.dev.method == VP_VOIGT_FAST)
+            hipLaunchKernelGGL((vp::walker_kernel2<1, SAMPLER>), grid, block, lds, s, d0, d1, in.dev.ntiles, c->inst[1].sum_logw, t0, a, st);
+        else
+            hipLaunchKernelGGL((vp::walker_kernel2<0, SAMPLER>), grid, block, lds, s, d0, d1, in.dev.ntiles, c->inst[1].sum_logw, t0, a, st);
+        return;
     }
+    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, SAMPLER>), grid, block, lds, s, d0, t0, a, st);
+    else if (keep_clusters) hipLaunchKernelGGL((vp::walker_kernel<0, true, false>), grid, block, lds, s, d0, t0, a, st);
+    else hipLaunchKernelGGL((vp::walker_kernel<0, false, SAMPLER>), grid, block, lds, s, d0, t0, a, st);
+}
+
+void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
+    const vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double))};
+    launch_walker_any<false>(c, W, a, vp::StretchArgs{}, s);
 }
 
 // One stretch-move half-step of the active half (nS walkers) as ONE launch: proposal, lnprob and accept/reject inside
 // each walker's workgroup (walker_kernel<.., SAMPLER = true>).
 void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStream_t s) {
-    const Instrument& in = c->inst[0];
-    vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc, nullptr, in.sum_logw, c->D, (int)(in.lds_bytes / sizeof(double))};
-    const dim3 grid(nS), block(64 * in.dev.ntiles);
-    const size_t lds = walker_lds_bytes(in);
-    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, true>), grid, block, lds, s, in.dev, in.lines, a, st);
-    else {
-        vp::InstDev d2 = in.dev; d2.NCm = 0;
-        vp::LinesDev t2 = in.lines; t2.NCm = 0;
-        hipLaunchKernelGGL((vp::walker_kernel<0, false, true>), grid, block, lds, s, d2, t2, a, st);
-    }
+    const vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc, nullptr, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double))};
+    launch_walker_any<true>(c, nS, a, st, s);
 }
 
 int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
@@ -512,6 +535,9 @@ int vp_ctx_create(vp_ctx** out, int device_id) {
     for (const void* f : {(const void*)vp::walker_kernel<0, false, false>, (const void*)vp::walker_kernel<0, true, false>,
                           (const void*)vp::walker_kernel<1, false, false>, (const void*)vp::walker_kernel<0, false, true>,
                           (const void*)vp::walker_kernel<1, false, true>,
+                          (const void*)vp::walker_kernel2<0, false>, (const void*)vp::walker_kernel2<0, true>,
+                          (const void*)vp::walker_kernel2<1, false>, (const void*)vp::walker_kernel2<1, true>,
+                          (const void*)vp::tile_kernel<0, 0, false, true>,
                           (const void*)vp::tile_kernel<0, 0, false>, (const void*)vp::tile_kernel<0, 0, true>,
                           (const void*)vp::tile_kernel<0, 1, false>, (const void*)vp::tile_kernel<0, 1, true>,
                           (const void*)vp::tile_kernel<0, 2, false>, (const void*)vp::tile_kernel<0, 2, true>,

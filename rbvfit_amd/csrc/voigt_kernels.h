@@ -1359,13 +1359,16 @@ struct WalkerArgs {
 //      tile order -- no ticket, no atomics, no finalize launch.
 // Used for single-instrument contexts whose prior box keeps every line in the fast domain, for batches
 // small enough that launch overheads matter (capi.hip: enqueue_lnprob).
-template <int METHOD, bool CLUSTERS, bool SAMPLER>   // CLUSTERS: the instrument has multipole cluster records (their
+template <int METHOD, bool CLUSTERS, bool SAMPLER, bool MULTI>   // CLUSTERS: the instrument has multipole cluster records (their
                                        // preparation needs more registers than the tile work and spills to scratch;
                                        // kept out of the plain instance).  SAMPLER: stretch-move half-step (StretchArgs)
 #ifndef VP_WALKER_WPE
 #define VP_WALKER_WPE 6
 #endif
-__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A, StretchArgs S) {
+// MULTI: a SECOND instrument with the same line tables (the walker's records serve both): waves tbase1 ... are its tiles,
+// I1 its geometry and spectrum, sum_logw1 its weight constant; the tile sums are added per instrument, in order, as
+// finalize_kernel does.
+__device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, int tbase1, double sum_logw1, LinesDev T, WalkerArgs A, StretchArgs S) {
     extern __shared__ double smem[];
     VP_STAMP_DECL
     VP_STAMP(0);
@@ -1406,12 +1409,15 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
             if (k < T.NCm) prep_cluster(A.theta + (size_t)w * A.D, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
         }
     }
-    const int p0 = wid * I.TP, nout = min(p0 + I.TP, I.P) - p0;
+    const bool second = MULTI && wid >= tbase1;                  // (wave-uniform)
+    const InstDev& I = second ? I1 : I0;
+    const int lt = second ? wid - tbase1 : wid;                  // tile of its instrument
+    const int p0 = lt * I.TP, nout = min(p0 + I.TP, I.P) - p0;
     const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
     fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = g_exp2_64[lane];   // the wave's exp table (EXP_LDS_DOUBLES = 64 entries),
                                                                            // staged while it waits for the records anyway
     // ... and the Dawson table where the tile met line cores before (1.2 us between phase A and phase B otherwise)
-    const bool daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(I.core_hint[wid]) != 0;
+    const bool daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(I.core_hint[lt]) != 0;
     if (daw_ready) dawson_to_lds(fl + I.span + FL_PAD + 4, lane, 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1438,8 +1444,14 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
         VP_STAMP(5);
         if (wid != 0) return;
         double sk = 0.0;
-        for (int k = 0; k < nw; ++k) sk += red[k];
+        const int n0 = MULTI ? tbase1 : nw;
+        for (int k = 0; k < n0; ++k) sk += red[k];
         total += -0.5 * (sk - A.sum_logw);         // vfit_mcmc.py:309-311
+        if (MULTI) {
+            double s1 = 0.0;
+            for (int k = tbase1; k < nw; ++k) s1 += red[k];
+            total += -0.5 * (s1 - sum_logw1);
+        }
     } else if (wid != 0) {
         return;
     }
@@ -1477,6 +1489,16 @@ __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kern
             if (lane == 0) S.chain_lp[ws] = accept ? lnp : lp_old;
         }
     }
+}
+
+template <int METHOD, bool CLUSTERS, bool SAMPLER>
+__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A, StretchArgs S) {
+    walker_body<METHOD, CLUSTERS, SAMPLER, false>(I, I, 0, 0.0, T, A, S);
+}
+template <int METHOD, bool SAMPLER>
+__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel2(InstDev I, InstDev I1, int tbase1, double sum_logw1,
+                                                                                   LinesDev T, WalkerArgs A, StretchArgs S) {
+    walker_body<METHOD, false, SAMPLER, true>(I, I1, tbase1, sum_logw1, T, A, S);
 }
 
 // Final reduction as a launch of its own (one lane per walker), used for batches so large that the two

@@ -230,3 +230,47 @@ def test_farfield_expansions_agree_with_direct_evaluation(seed):
     for k in (0, 1):
         np.testing.assert_allclose(got[1][k], got[0][k], rtol=1e-12, atol=1e-9)
         np.testing.assert_allclose(got[1][k], ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+
+
+def test_two_instruments_in_one_walker_launch():
+    """Two instruments with the same line tables and at most 16 tiles together run as ONE walker_kernel launch (waves of
+    the second instrument behind those of the first, one set of records): against the oracle and, tile for tile the same
+    arithmetic, bit-identical to the preparation + tile + finalize launches."""
+    import rbvfit_amd
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    rng = np.random.default_rng(17)
+    cfg = FitConfiguration()
+    cfg.add_system(0.348, "MgII", [2796.352, 2803.531], 2)
+    C = cfg.total_components
+    theta = np.array([13.5, 13.2, 15.0, 25.0, -40.0, 20.0])
+    lb = np.concatenate([np.full(C, 10.0), np.full(C, 2.0), np.full(C, -300.0)])
+    ub = np.concatenate([np.full(C, 17.0), np.full(C, 100.0), np.full(C, 300.0)])
+    thetas = np.clip(theta + 1e-2 * rng.standard_normal((40, 3 * C)), lb + 1e-9, ub - 1e-9)
+    thetas[5, 0] = 25.0                                        # one walker outside the box
+    insts, engine_args = [], []
+    for fwhm, wave in (("6.5", np.linspace(3755.0, 3795.0, 2500)), ("3.0", np.linspace(3760.0, 3790.0, 1400))):
+        data = VoigtModel(cfg, FWHM=fwhm).compile().data
+        od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors, data.N_indices,
+                                data.b_indices, data.v_indices, data.taps, data.lsf_mode, data.voigt_method)
+        err = np.full(wave.size, 0.04)
+        flux = vo.model_flux(od, theta, wave) + rng.normal(0, 0.04, wave.size)
+        oi = vo.OracleInstrument.from_error(od, wave, flux, err)
+        insts.append(oi); engine_args.append((wave, flux, oi, data))
+    ref = vo.lnprob_batch(thetas, lb, ub, insts)
+    with rbvfit_amd.Engine(0) as e:
+        e.set_bounds(lb, ub)
+        for wave, flux, oi, data in engine_args:
+            e.add_instrument(wave, flux, oi.inv_sigma2, oi.log_inv_sigma2, **data.engine_kwargs())
+        got = e.lnprob(thetas)
+        assert e.last_launch_kind == "walker"
+        e.set_option("walker", 0); e.set_option("geom", 0); e.set_option("finalize", 0)
+        launches = e.lnprob(thetas)
+        assert e.last_launch_kind == "tiles"
+        e.set_option("walker", -1)
+        pos, lp, chain, clp, nacc = e.stretch_run(thetas[:32], 12, seed=4)        # half-steps as one launch each
+        e.set_option("geom", 0)
+        np.testing.assert_array_equal(clp[-1], e.lnprob(chain[-1]))
+    assert got[5] == -np.inf and launches[5] == -np.inf
+    np.testing.assert_array_equal(got, launches)
+    np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
