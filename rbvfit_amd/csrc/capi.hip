@@ -71,6 +71,10 @@ Tuning tuning_from_env() {
 struct Instrument {
     vp::InstDev dev{};
     vp::InstDev dev_s{};         // same instrument, one-pass tiles: used for small batches (lnprob only)
+    vp::InstDev dev_w{};         // walker_kernel's geometry: single-wave tiles of 384 evaluated pixels whatever the LSF
+                                 // length (= dev for K <= 33; longer LSFs: more halo per tile, but one launch)
+    size_t lds_w = 0;            // LDS bytes of one such tile; 0: the LSF is too long for single-wave tiles
+
     vp::LinesDev lines{};
     double sum_logw = 0.0;
     std::vector<void*> allocs;   // device allocations owned by this instrument
@@ -323,12 +327,12 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
 // (one or two instruments: a second one must have the first one's line tables -- the walker's records serve both)
 int walker_tiles(const vp_ctx* c) {
     int n = 0;
-    for (auto& in : c->inst) n += in.dev.ntiles;
+    for (auto& in : c->inst) n += in.dev_w.ntiles;
     return n;
 }
 size_t walker_wave_lds(const vp_ctx* c) {
     size_t b = 0;
-    for (auto& in : c->inst) b = std::max(b, in.lds_bytes);
+    for (auto& in : c->inst) b = std::max(b, in.lds_w);
     return b;
 }
 size_t walker_lds_bytes(const vp_ctx* c) {           // tiles | tile sums, prior flag, spare
@@ -342,7 +346,7 @@ bool walker_applies(const vp_ctx* c, int W) {
     if (c->tune.walker == 0 || c->inst.empty() || c->inst.size() > 2 || c->D > 64) return false;
     const Instrument& in = c->inst[0];
     for (auto& k : c->inst) {
-        if (k.nwaves != 1 || k.dev.method != in.dev.method) return false;
+        if (k.lds_w == 0 || k.dev.method != in.dev.method) return false;
         if (k.dev.method == VP_VOIGT_WOFZ && k.needs_generic) return false;
     }
     if (c->inst.size() == 2 && (!c->inst[1].same_lines_as_prev || c->tune.walker_clusters)) return false;
@@ -351,6 +355,11 @@ bool walker_applies(const vp_ctx* c, int W) {
     if (walker_lds_bytes(c) > c->lds_limit) return false;
     if (c->tune.walker == 1) return true;
     if (in.dev.NCm > 0 && (c->tune.walker_clusters || in.dev.L > VP_WALKER_MAX_CLUSTER_LINES)) return false;
+    // LSFs of more than 33 taps: the launches use 2- or 4-wave tile workgroups, the walker kernel single-wave tiles with
+    // more halo -- measured on 2100 pixels, us per pass, launches / walker kernel: 45 taps 64 walkers 17.8 / 18.1,
+    // 256: 20.5 / 18.2, 512: 26.9 / 22.0; 101 taps 19.4 / 22.1, 23.9 / 22.2, 35.0 / 32.1
+    for (auto& k : c->inst)
+        if (k.nwaves != 1 && W < 192) return false;
     // a CU holds per_cu walker workgroups at once (24 wave slots / waves per walker, LDS permitting); the batch lies
     // on the 256 CUs in layers of 256 workgroups and the launch takes as long as the fullest CU's layers
     const int per_cu = std::max(1, std::min(24 / std::max(1, nt), (int)(c->lds_limit / walker_lds_bytes(c))));
@@ -365,17 +374,17 @@ void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::Stre
     const Instrument& in = c->inst[0];
     const dim3 grid(W), block(64 * walker_tiles(c));
     const size_t lds = walker_lds_bytes(c);
-    vp::InstDev d0 = in.dev;
+    vp::InstDev d0 = in.dev_w;
     vp::LinesDev t0 = in.lines;
     const bool keep_clusters = in.dev.NCm > 0 && c->tune.walker_clusters && !SAMPLER && c->inst.size() == 1;
     if (!keep_clusters) { d0.NCm = 0; t0.NCm = 0; }
     if (c->inst.size() == 2) {
-        vp::InstDev d1 = c->inst[1].dev;
+        vp::InstDev d1 = c->inst[1].dev_w;
         d1.NCm = 0;
         if (in.dev.method == VP_VOIGT_FAST)
-            hipLaunchKernelGGL((vp::walker_kernel2<1, SAMPLER>), grid, block, lds, s, d0, d1, in.dev.ntiles, c->inst[1].sum_logw, t0, a, st);
+            hipLaunchKernelGGL((vp::walker_kernel2<1, SAMPLER>), grid, block, lds, s, d0, d1, d0.ntiles, c->inst[1].sum_logw, t0, a, st);
         else
-            hipLaunchKernelGGL((vp::walker_kernel2<0, SAMPLER>), grid, block, lds, s, d0, d1, in.dev.ntiles, c->inst[1].sum_logw, t0, a, st);
+            hipLaunchKernelGGL((vp::walker_kernel2<0, SAMPLER>), grid, block, lds, s, d0, d1, d0.ntiles, c->inst[1].sum_logw, t0, a, st);
         return;
     }
     if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, SAMPLER>), grid, block, lds, s, d0, t0, a, st);
@@ -733,6 +742,21 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         }
     }
     in.lds_bytes = (size_t)(span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
+    {
+        in.dev_w = in.dev;
+        in.lds_w = in.lds_bytes;
+        if (in.nwaves != 1) {
+            const int span_w = 2 * 64 * vp::RB;
+            if (span_w - (Kuse - 1) >= 64 && c->tune.span == 0) {
+                in.dev_w.span = span_w; in.dev_w.TP = span_w - (Kuse - 1);
+                in.dev_w.ntiles = (P + in.dev_w.TP - 1) / in.dev_w.TP;
+                in.dev_w.ff_tab = nullptr; in.dev_w.ff_nblk = 0;
+                in.lds_w = (size_t)(span_w + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + vp::EXP_LDS_DOUBLES + (span_w / 64) * ((L + 63) / 64)) * sizeof(double);
+            } else {
+                in.lds_w = 0;
+            }
+        }
+    }
     if (in.lds_bytes + (size_t)std::max(0l, c->tune.lds_pad) > c->lds_limit) {
         for (void* p : in.allocs) hipFree(p);
         return fail(c, VP_EINVAL, "vp_add_instrument: a " + std::to_string(Kuse) + "-tap LSF with " + std::to_string(L) +

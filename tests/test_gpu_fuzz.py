@@ -274,3 +274,48 @@ def test_two_instruments_in_one_walker_launch():
     assert got[5] == -np.inf and launches[5] == -np.inf
     np.testing.assert_array_equal(got, launches)
     np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+
+
+@pytest.mark.parametrize("kind", ["gauss45", "tab101"])
+def test_long_lsf_in_the_walker_kernel(kind):
+    """LSFs longer than 33 taps make the tile LAUNCHES use 2- or 4-wave workgroups; the walker kernel keeps single-wave
+    tiles of 384 evaluated pixels (more halo, one launch).  Different tiles, so agreement with the launches is to rounding;
+    both against the oracle."""
+    import rbvfit_amd
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    from rbvfit_amd.workloads import cos_like_kernel
+    rng = np.random.default_rng(23)
+    cfg = FitConfiguration()
+    cfg.add_system(0.348, "MgII", [2796.352, 2803.531], 2)
+    model = VoigtModel(cfg, FWHM="13.0") if kind == "gauss45" else VoigtModel(cfg, FWHM="6.5", kernel_taps=cos_like_kernel())
+    data = model.compile().data
+    assert (data.taps.size > 33)
+    theta = np.array([13.5, 13.2, 15.0, 25.0, -40.0, 20.0])
+    lb = np.concatenate([np.full(2, 10.0), np.full(2, 2.0), np.full(2, -300.0)])
+    ub = np.concatenate([np.full(2, 17.0), np.full(2, 100.0), np.full(2, 300.0)])
+    thetas = np.clip(theta + 1e-2 * rng.standard_normal((24, 6)), lb + 1e-9, ub - 1e-9)
+    wave = np.linspace(3760.0, 3790.0, 2100)
+    od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors, data.N_indices,
+                            data.b_indices, data.v_indices, data.taps, data.lsf_mode, data.voigt_method)
+    err = np.full(wave.size, 0.04)
+    flux = vo.model_flux(od, theta, wave) + rng.normal(0, 0.04, wave.size)
+    oi = vo.OracleInstrument.from_error(od, wave, flux, err)
+    ref = vo.lnprob_batch(thetas, lb, ub, [oi])
+    with rbvfit_amd.Engine(0) as e:
+        e.set_bounds(lb, ub)
+        e.add_instrument(wave, flux, oi.inv_sigma2, oi.log_inv_sigma2, **data.engine_kwargs())
+        e.set_option("walker", 1)                     # (by default only from 192 walkers on for these LSFs)
+        got = e.lnprob(thetas)
+        assert e.last_launch_kind == "walker"
+        e.set_option("walker", 0)
+        launches = e.lnprob(thetas)
+        assert e.last_launch_kind == "tiles"
+        e.set_option("walker", -1)
+        big = np.tile(thetas, (10, 1))
+        got_big = e.lnprob(big)
+        assert e.last_launch_kind == "walker"
+    np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    np.testing.assert_allclose(launches, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    np.testing.assert_allclose(got, launches, rtol=1e-13, atol=0)
+    np.testing.assert_array_equal(got_big, np.tile(got, 10))
