@@ -339,9 +339,9 @@ size_t walker_lds_bytes(const vp_ctx* c) {           // tiles | tile sums, prior
     return (size_t)walker_tiles(c) * walker_wave_lds(c) + (walker_tiles(c) + 2) * sizeof(double);
 }
 
-#ifndef VP_WALKER_MAX_CLUSTER_LINES
-#define VP_WALKER_MAX_CLUSTER_LINES 64
-#endif
+#ifndef VP_WALKER_MAX_LINES
+#define VP_WALKER_MAX_LINES 40        // above: the launches win (multipoles, far-field expansions, finer scheduling) -- 5000 pixels,
+#endif                                // 256 walkers, us per pass, walker kernel / launches: 20 lines 38.7 / 49.6, 40: 67.9 / 69.9, 64: 105.8 / 99.0
 bool walker_applies(const vp_ctx* c, int W) {
     if (c->tune.walker == 0 || c->inst.empty() || c->inst.size() > 2 || c->D > 64) return false;
     const Instrument& in = c->inst[0];
@@ -354,7 +354,7 @@ bool walker_applies(const vp_ctx* c, int W) {
     if (nt > vp::WALKER_THREADS_MAX / 64) return false;
     if (walker_lds_bytes(c) > c->lds_limit) return false;
     if (c->tune.walker == 1) return true;
-    if (in.dev.NCm > 0 && (c->tune.walker_clusters || in.dev.L > VP_WALKER_MAX_CLUSTER_LINES)) return false;
+    if (in.dev.L > VP_WALKER_MAX_LINES || (in.dev.NCm > 0 && c->tune.walker_clusters)) return false;
     // LSFs of more than 33 taps: the launches use 2- or 4-wave tile workgroups, the walker kernel single-wave tiles with
     // more halo -- measured on 2100 pixels, us per pass, launches / walker kernel: 45 taps 64 walkers 17.8 / 18.1,
     // 256: 20.5 / 18.2, 512: 26.9 / 22.0; 101 taps 19.4 / 22.1, 23.9 / 22.2, 35.0 / 32.1
