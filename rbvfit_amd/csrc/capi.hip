@@ -38,7 +38,7 @@ struct Tuning {
     long lds_pad = 0;           // extra LDS bytes per tile workgroup: occupancy experiments
     int no_fused_accept = 0;    // device sampler: separate accept / propose launches
     int farfield = -1;          // far-field expansions in the tile launches: -1 for instruments with >= 8 lines and batches
-                                // with walkers x blocks x lines >= 4e5, 0 never, 1 whenever possible (the instrument's
+                                // with enough covered (walker, block, item) triples (enqueue_lnprob), 0 never, 1 whenever possible (the instrument's
                                 // block tables are made when it is added: 0 at that time rules them out for good)
     int walker_clusters = 0;    // walker_kernel on instruments with multipole clusters: 0 = walk the member lines one by one
                                 // (no cluster records: the plain instance), 1 = cluster records formed in the workgroup
@@ -87,6 +87,8 @@ struct Instrument {
     bool needs_generic = true;
     int nwaves = 1;              // waves per tile workgroup (1, 2 or 4)
     bool ff_on = false;          // far-field expansions (farfield_kernel + the FF instance of tile_kernel) for lnprob
+    double ff_cover = 0.0;       // estimated share of (block, line) pairs the expansions cover (host, prior-box centre)
+    int ff_items = 0;            // multipole clusters + lines outside clusters: what a pass of the tile kernel walks
     std::vector<double> h_lines; // lambda0 | gamma | f | zfac: with h_idx, what the line records of a walker depend on
     std::vector<int> h_idx;      // N_idx | b_idx | v_idx | method | multipole settings
     bool same_lines_as_prev = false;   // this instrument's records ARE the previous instrument's (same line tables):
@@ -120,6 +122,7 @@ struct vp_ctx {
     double* d_ff = nullptr;      // (capW, cap_ffblk, FF_STRIDE) far-field expansions of the instrument being evaluated
     int cap_ffblk = 0;
     std::vector<double> h_lb;    // host copy of the lower bounds
+    std::vector<double> h_ub;    // ... and of the upper bounds
     int* d_tile_off = nullptr;   // 2 x (n_inst + 1): tile offsets of the full-size and of the one-pass geometry
     double* d_sum_logw = nullptr;
     bool meta_dirty = true;
@@ -447,8 +450,13 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         const vp::InstDev& geom = sel ? in.dev_s : in.dev;
         // (the extra launch costs ~20 us; what it saves grows with walkers x blocks x lines -- measured on C2, us per pass
         // without / with: 128 walkers 54.8 / 60.5, 256 (0.42e6): 72.7 / 71.5, 512: 111.8 / 98.3, 1024: 188.8 / 153.1,
-        // 2048: 349.0 / 260.5.  Below 4e5 the lines are walked directly unless "farfield" = 1 asks for the expansions)
-        const bool ff_pays = c->tune.farfield > 0 || (long)W * geom.ntiles * geom.ff_nblk * in.dev.L >= 400000l;
+        // 2048: 349.0 / 260.5.  Below that the lines are walked directly unless "farfield" = 1 asks for the expansions.
+        // What the expansions save is one evaluation per pass for every ITEM they cover (a multipole cluster or a line
+        // outside clusters: C2 has 9, a 40-line FeII fit of 8 clusters 8, one of 20 lines 4), ff_cover of them (estimated
+        // when the instrument is added); the crossover sits near 2e5 covered (walker, block, item) triples: C2 at 256
+        // walkers (0.195e6) 72.7 / 71.5 us, the 40-line FeII fit at 1024 walkers (0.17e6) 164.9 / 161.1, the 20-line one
+        // at 1024 (0.09e6) 90.4 / 93.2.
+        const bool ff_pays = c->tune.farfield > 0 || in.ff_cover * (double)W * geom.ntiles * geom.ff_nblk * in.ff_items >= 2.0e5;
         double* ff = (in.ff_on && c->d_ff && ff_pays) ? c->d_ff : nullptr;
         if (ff) {                                        // the blocks' far-field expansions from the records just made
             c->last_kind = 2;
@@ -606,6 +614,7 @@ int vp_set_bounds(vp_ctx* c, int D, const double* lb, const double* ub) {
     }
     c->D = D;
     c->h_lb.assign(lb, lb + D);
+    c->h_ub.assign(ub, ub + D);
     for (auto& in : c->inst) analyse_generic(c, in);
     return VP_OK;
 }
@@ -739,6 +748,34 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
             double* d_tab;
             if ((rc = upload<double>(c, &in, tab.data(), tab.size(), &d_tab))) { for (void* p : in.allocs) hipFree(p); return rc; }
             gd->ff_tab = d_tab; gd->ff_nblk = nblk; gd->ff = nullptr;
+            if (gd == &in.dev) {
+                // how much of the instrument the expansions will cover, estimated for Doppler widths at the geometric
+                // centre of their bounds and lines at rest in their systems: the acceptance rule of farfield_kernel in
+                // velocity units (block half-width <= distance / 8, nearest pixel >= 30 Doppler widths away)
+                const double ckms = 299792.458;
+                long cov = 0, tot = 0;
+                for (size_t bk = 0; bk < tab.size() / 4; ++bk) {
+                    const double gc = tab[4 * bk], hw = tab[4 * bk + 1];
+                    if (!(hw >= 0.0) || !(gc > 0.0)) continue;
+                    const double hwv = ckms * hw / gc;
+                    for (int l = 0; l < L; ++l) {
+                        const double lam = lambda0[l] * zfac[l];
+                        double bl = c->h_lb[b_idx[l]], bu = c->h_ub.size() == c->h_lb.size() ? c->h_ub[b_idx[l]] : bl;
+                        const double beff = (bl > 0.0 && bu > 0.0) ? std::sqrt(bl * bu) : 20.0;
+                        const double dv = ckms * std::fabs(std::log(1.0 / (gc * lam)));
+                        ++tot;
+                        if (hwv <= dv / 8.0 && dv - hwv >= 30.0 * beff) ++cov;
+                    }
+                }
+                in.ff_cover = tot > 0 ? (double)cov / (double)tot : 0.0;
+                {
+                    int members = 0;
+                    for (size_t k = 0; k < cl_count.size(); ++k) members += cl_count[k];
+                    in.ff_items = (int)cl_count.size() + (L - members);
+                }
+                if (getenv("RBVFIT_AMD_VERBOSE")) fprintf(stderr, "[rbvfit_amd] instrument %zu: far-field cover estimate %.3f (%d lines, %zu blocks)\n",
+                                                          c->inst.size(), in.ff_cover, L, tab.size() / 4);
+            }
         }
     }
     in.lds_bytes = (size_t)(span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
