@@ -211,7 +211,7 @@ int vp_ndim(const vp_ctx* ctx);
 int vp_instrument_pixels(const vp_ctx* ctx, int inst);
 int vp_device_id(const vp_ctx* ctx);
 /* Launch structure the last lnprob batch used: 0 = prep_lines_kernel + tile_kernel (+ finalize_kernel),
- * 1 = walker_kernel (the whole batch in one launch: one instrument, or two with identical line tables), 2 = as 0 with farfield_kernel between preparation and tiles
+ * 1 = walker_kernel (the whole batch in one launch: one instrument, or up to four with identical line tables), 2 = as 0 with farfield_kernel between preparation and tiles
  * (far lines from per-block expansions). */
 int vp_last_launch_kind(const vp_ctx* ctx);
 

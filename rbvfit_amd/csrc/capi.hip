@@ -346,13 +346,14 @@ size_t walker_lds_bytes(const vp_ctx* c) {           // tiles | tile sums, prior
 #define VP_WALKER_MAX_LINES 40        // above: the launches win (multipoles, far-field expansions, finer scheduling) -- 5000 pixels,
 #endif                                // 256 walkers, us per pass, walker kernel / launches: 20 lines 38.7 / 49.6, 40: 67.9 / 69.9, 64: 105.8 / 99.0
 bool walker_applies(const vp_ctx* c, int W) {
-    if (c->tune.walker == 0 || c->inst.empty() || c->inst.size() > 2 || c->D > 64) return false;
+    if (c->tune.walker == 0 || c->inst.empty() || c->inst.size() > 4 || c->D > 64) return false;
     const Instrument& in = c->inst[0];
     for (auto& k : c->inst) {
         if (k.lds_w == 0 || k.dev.method != in.dev.method) return false;
         if (k.dev.method == VP_VOIGT_WOFZ && k.needs_generic) return false;
     }
-    if (c->inst.size() == 2 && (!c->inst[1].same_lines_as_prev || c->tune.walker_clusters)) return false;
+    for (size_t k = 1; k < c->inst.size(); ++k)
+        if (!c->inst[k].same_lines_as_prev || c->tune.walker_clusters) return false;
     const int nt = walker_tiles(c);
     if (nt > vp::WALKER_THREADS_MAX / 64) return false;
     if (walker_lds_bytes(c) > c->lds_limit) return false;
@@ -381,13 +382,26 @@ void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::Stre
     vp::LinesDev t0 = in.lines;
     const bool keep_clusters = in.dev.NCm > 0 && c->tune.walker_clusters && !SAMPLER && c->inst.size() == 1;
     if (!keep_clusters) { d0.NCm = 0; t0.NCm = 0; }
-    if (c->inst.size() == 2) {
-        vp::InstDev d1 = c->inst[1].dev_w;
-        d1.NCm = 0;
-        if (in.dev.method == VP_VOIGT_FAST)
-            hipLaunchKernelGGL((vp::walker_kernel2<1, SAMPLER>), grid, block, lds, s, d0, d1, d0.ntiles, c->inst[1].sum_logw, t0, a, st);
-        else
-            hipLaunchKernelGGL((vp::walker_kernel2<0, SAMPLER>), grid, block, lds, s, d0, d1, d0.ntiles, c->inst[1].sum_logw, t0, a, st);
+    if (c->inst.size() > 1) {
+        vp::InstDev dk[4] = {d0, d0, d0, d0};
+        vp::WalkerMore tb{};
+        int tsum = d0.ntiles;
+        for (size_t k = 1; k < c->inst.size(); ++k) {
+            dk[k] = c->inst[k].dev_w;
+            dk[k].NCm = 0;
+            tb.t[k - 1] = tsum;
+            tb.slw[k - 1] = c->inst[k].sum_logw;
+            tsum += dk[k].ntiles;
+        }
+        for (size_t k = c->inst.size(); k < 4; ++k) tb.t[k - 1] = tsum;        // (no tiles)
+        const bool fast = in.dev.method == VP_VOIGT_FAST;
+        if (c->inst.size() == 2) {
+            if (fast) hipLaunchKernelGGL((vp::walker_kernel2<1, SAMPLER>), grid, block, lds, s, dk[0], dk[1], tb, t0, a, st);
+            else hipLaunchKernelGGL((vp::walker_kernel2<0, SAMPLER>), grid, block, lds, s, dk[0], dk[1], tb, t0, a, st);
+        } else {
+            if (fast) hipLaunchKernelGGL((vp::walker_kernel4<1, SAMPLER>), grid, block, lds, s, dk[0], dk[1], dk[2], dk[3], tb, t0, a, st);
+            else hipLaunchKernelGGL((vp::walker_kernel4<0, SAMPLER>), grid, block, lds, s, dk[0], dk[1], dk[2], dk[3], tb, t0, a, st);
+        }
         return;
     }
     if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, SAMPLER>), grid, block, lds, s, d0, t0, a, st);
@@ -554,6 +568,8 @@ int vp_ctx_create(vp_ctx** out, int device_id) {
                           (const void*)vp::walker_kernel<1, false, true>,
                           (const void*)vp::walker_kernel2<0, false>, (const void*)vp::walker_kernel2<0, true>,
                           (const void*)vp::walker_kernel2<1, false>, (const void*)vp::walker_kernel2<1, true>,
+                          (const void*)vp::walker_kernel4<0, false>, (const void*)vp::walker_kernel4<0, true>,
+                          (const void*)vp::walker_kernel4<1, false>, (const void*)vp::walker_kernel4<1, true>,
                           (const void*)vp::tile_kernel<0, 0, false, true>,
                           (const void*)vp::tile_kernel<0, 0, false>, (const void*)vp::tile_kernel<0, 0, true>,
                           (const void*)vp::tile_kernel<0, 1, false>, (const void*)vp::tile_kernel<0, 1, true>,

@@ -1359,16 +1359,17 @@ struct WalkerArgs {
 //      tile order -- no ticket, no atomics, no finalize launch.
 // Used for single-instrument contexts whose prior box keeps every line in the fast domain, for batches
 // small enough that launch overheads matter (capi.hip: enqueue_lnprob).
-template <int METHOD, bool CLUSTERS, bool SAMPLER, bool MULTI>   // CLUSTERS: the instrument has multipole cluster records (their
+// NI > 1: further instruments with the same line tables (the walker's records serve all): waves tb.t[k-1] ... are the
+// tiles of instrument k, Ik its geometry and spectrum, tb.slw[k-1] its weight constant; the tile sums are added per
+// instrument, in order, as finalize_kernel does.
+struct WalkerMore { int t[3]; double slw[3]; };
+template <int METHOD, bool CLUSTERS, bool SAMPLER, int NI>   // CLUSTERS: the instrument has multipole cluster records (their
                                        // preparation needs more registers than the tile work and spills to scratch;
                                        // kept out of the plain instance).  SAMPLER: stretch-move half-step (StretchArgs)
 #ifndef VP_WALKER_WPE
 #define VP_WALKER_WPE 6
 #endif
-// MULTI: a SECOND instrument with the same line tables (the walker's records serve both): waves tbase1 ... are its tiles,
-// I1 its geometry and spectrum, sum_logw1 its weight constant; the tile sums are added per instrument, in order, as
-// finalize_kernel does.
-__device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, int tbase1, double sum_logw1, LinesDev T, WalkerArgs A, StretchArgs S) {
+__device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, InstDev I3, WalkerMore tb, LinesDev T, WalkerArgs A, StretchArgs S) {
     extern __shared__ double smem[];
     VP_STAMP_DECL
     VP_STAMP(0);
@@ -1409,9 +1410,10 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, int tbase1, 
             if (k < T.NCm) prep_cluster(A.theta + (size_t)w * A.D, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
         }
     }
-    const bool second = MULTI && wid >= tbase1;                  // (wave-uniform)
-    const InstDev& I = second ? I1 : I0;
-    const int lt = second ? wid - tbase1 : wid;                  // tile of its instrument
+    // (wave-uniform) which instrument this wave's tile belongs to
+    const int ki = (NI > 1 && wid >= tb.t[0]) ? ((NI > 2 && wid >= tb.t[1]) ? ((NI > 3 && wid >= tb.t[2]) ? 3 : 2) : 1) : 0;
+    const InstDev& I = ki == 0 ? I0 : (ki == 1 ? I1 : (ki == 2 ? I2 : I3));
+    const int lt = ki == 0 ? wid : wid - tb.t[ki - 1];            // tile of its instrument
     const int p0 = lt * I.TP, nout = min(p0 + I.TP, I.P) - p0;
     const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
     fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = g_exp2_64[lane];   // the wave's exp table (EXP_LDS_DOUBLES = 64 entries),
@@ -1444,13 +1446,14 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, int tbase1, 
         VP_STAMP(5);
         if (wid != 0) return;
         double sk = 0.0;
-        const int n0 = MULTI ? tbase1 : nw;
+        const int n0 = NI > 1 ? tb.t[0] : nw;
         for (int k = 0; k < n0; ++k) sk += red[k];
         total += -0.5 * (sk - A.sum_logw);         // vfit_mcmc.py:309-311
-        if (MULTI) {
-            double s1 = 0.0;
-            for (int k = tbase1; k < nw; ++k) s1 += red[k];
-            total += -0.5 * (s1 - sum_logw1);
+        for (int j = 1; j < NI; ++j) {
+            double sj = 0.0;
+            const int a0 = tb.t[j - 1], a1 = j + 1 < NI ? tb.t[j] : nw;
+            for (int k = a0; k < a1; ++k) sj += red[k];
+            total += -0.5 * (sj - tb.slw[j - 1]);
         }
     } else if (wid != 0) {
         return;
@@ -1493,12 +1496,17 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, int tbase1, 
 
 template <int METHOD, bool CLUSTERS, bool SAMPLER>
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A, StretchArgs S) {
-    walker_body<METHOD, CLUSTERS, SAMPLER, false>(I, I, 0, 0.0, T, A, S);
+    walker_body<METHOD, CLUSTERS, SAMPLER, 1>(I, I, I, I, WalkerMore{}, T, A, S);
 }
 template <int METHOD, bool SAMPLER>
-__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel2(InstDev I, InstDev I1, int tbase1, double sum_logw1,
+__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel2(InstDev I, InstDev I1, WalkerMore tb, LinesDev T, WalkerArgs A,
+                                                                                   StretchArgs S) {
+    walker_body<METHOD, false, SAMPLER, 2>(I, I1, I1, I1, tb, T, A, S);
+}
+template <int METHOD, bool SAMPLER>      // three or four instruments
+__global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel4(InstDev I, InstDev I1, InstDev I2, InstDev I3, WalkerMore tb,
                                                                                    LinesDev T, WalkerArgs A, StretchArgs S) {
-    walker_body<METHOD, false, SAMPLER, true>(I, I1, tbase1, sum_logw1, T, A, S);
+    walker_body<METHOD, false, SAMPLER, 4>(I, I1, I2, I3, tb, T, A, S);
 }
 
 // Final reduction as a launch of its own (one lane per walker), used for batches so large that the two

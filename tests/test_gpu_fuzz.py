@@ -232,10 +232,11 @@ def test_farfield_expansions_agree_with_direct_evaluation(seed):
         np.testing.assert_allclose(got[1][k], ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
 
 
-def test_two_instruments_in_one_walker_launch():
-    """Two instruments with the same line tables and at most 16 tiles together run as ONE walker_kernel launch (waves of
-    the second instrument behind those of the first, one set of records): against the oracle and, tile for tile the same
-    arithmetic, bit-identical to the preparation + tile + finalize launches."""
+@pytest.mark.parametrize("n_inst", [2, 3, 4])
+def test_several_instruments_in_one_walker_launch(n_inst):
+    """Up to four instruments with the same line tables and at most 16 tiles together run as ONE walker_kernel launch
+    (the waves of each further instrument behind those of the one before, one set of records): against the oracle and, tile
+    for tile the same arithmetic, bit-identical to the preparation + tile + finalize launches."""
     import rbvfit_amd
     from oracle import voigt_oracle as vo
     from rbvfit_amd.model import FitConfiguration, VoigtModel
@@ -249,7 +250,9 @@ def test_two_instruments_in_one_walker_launch():
     thetas = np.clip(theta + 1e-2 * rng.standard_normal((40, 3 * C)), lb + 1e-9, ub - 1e-9)
     thetas[5, 0] = 25.0                                        # one walker outside the box
     insts, engine_args = [], []
-    for fwhm, wave in (("6.5", np.linspace(3755.0, 3795.0, 2500)), ("3.0", np.linspace(3760.0, 3790.0, 1400))):
+    specs = [("6.5", np.linspace(3755.0, 3795.0, 2500)), ("3.0", np.linspace(3760.0, 3790.0, 1400)),
+             ("4.0", np.linspace(3764.0, 3774.0, 700)[::-1].copy()), (None, np.linspace(3775.0, 3785.0, 500))][:n_inst]
+    for fwhm, wave in specs:
         data = VoigtModel(cfg, FWHM=fwhm).compile().data
         od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors, data.N_indices,
                                 data.b_indices, data.v_indices, data.taps, data.lsf_mode, data.voigt_method)
