@@ -40,6 +40,7 @@ struct Tuning {
     int farfield = -1;          // far-field expansions in the tile launches: -1 for instruments with >= 8 lines and batches
                                 // with enough covered (walker, block, item) triples (enqueue_lnprob), 0 never, 1 whenever possible (the instrument's
                                 // block tables are made when it is added: 0 at that time rules them out for good)
+    int no_shared_prep = 0;     // instruments with the previous one's line tables prepare their records again anyway
     int walker_clusters = 0;    // walker_kernel on instruments with multipole clusters: 0 = walk the member lines one by one
                                 // (no cluster records: the plain instance), 1 = cluster records formed in the workgroup
                                 // (that instance spills to scratch)
@@ -54,7 +55,7 @@ const Knob g_knobs[] = {
     VP_KNOB(zerocopy_max, "RBVFIT_AMD_ZEROCOPY_MAX", 1),
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
-    VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0),
+    VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
@@ -456,7 +457,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
-        if (!(k > 0 && in.same_lines_as_prev)) {       // (same line tables as the previous instrument: its records and
+        if (!(k > 0 && in.same_lines_as_prev && !c->tune.no_shared_prep)) {       // (same line tables as the previous instrument: its records and
                                                        // generic-path flags are still in the workspace)
             if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
             launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr, s);

@@ -902,6 +902,11 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     const int nchunks = (n_eval + 63) >> 6;
     if (first && tid < EXP_LDS_DOUBLES) etab[tid] = PRE ? pre.e2 : g_exp2_64[tid];
     if (tid < FL_PAD) fl[n_eval + tid] = 0.0;   // what the zero taps multiply must be finite
+    // Multi-wave tiles: the exp table is staged by the first wave and read by ALL waves at the end of their first pass.
+    // A pass used to be long enough for that never to matter; with the far-field expansions a pass over a block
+    // without near lines is ~60 instructions, and a wave could read the table before it was there (C3's 4-wave
+    // instrument: one wrong walker in ~1000 launches, caught by the full-size test's repeat check).
+    if (!SOLO && nwaves > 1) __syncthreads();
 
     // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
     //      Each wave owns 3 x 64 consecutive evaluated pixels per pass (RB chunks); lines are the

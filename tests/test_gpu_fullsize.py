@@ -377,3 +377,22 @@ def test_integration_md_binding_stub_runs_as_written():
     np.testing.assert_allclose(got[fin], z["lnprob"][fin], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     assert np.array_equal(np.isneginf(got), np.isneginf(z["lnprob"]))
     assert isinstance(post(z["thetas"][0]), float)
+
+
+def test_every_launch_gives_the_same_bits_under_permutations():
+    """1200 launches of C3 at its walker count (two instruments, one with 4-wave tile workgroups, far-field expansions) over
+    random permutations of the same walkers: every row must come out with the same bits every time.  (A wave of a 4-wave
+    tile once read the exp table before the first wave had staged it -- one wrong walker in ~700 launches.)"""
+    from rbvfit_amd.workloads import make_workload
+    wl = make_workload("C3", walkers=2048)
+    try:
+        th = wl.thetas.copy()
+        th[5, 0] = wl.lb[0] - 0.25
+        got = wl.engine.lnprob(th)
+        assert wl.engine.last_launch_kind == "tiles+farfield"
+        rng = np.random.default_rng(5)
+        for _ in range(1200):
+            perm = rng.permutation(th.shape[0])
+            assert np.array_equal(wl.engine.lnprob(th[perm]), got[perm])
+    finally:
+        wl.engine.close()
