@@ -91,7 +91,9 @@ def test_random_configuration(seed):
     np.testing.assert_allclose(got, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     np.testing.assert_allclose(got_big, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     clustered = any(g.components >= 3 for s in model.config.systems for g in s.ion_groups)
-    if data.n_lines < 8 and not clustered:
+    same_tiles = data.taps is None or data.taps.size <= 33     # (longer LSFs: 2-/4-wave tile workgroups in the launches,
+                                                               # single-wave tiles in the walker kernel)
+    if data.n_lines < 8 and not clustered and same_tiles:
         np.testing.assert_array_equal(got_walker, got_big)     # same tiles, same summation order: bit-identical
     else:       # the tile launches use multipole expansions of clusters (>= 3 components of a transition) and, from 8 lines
                 # on, per-block far-field expansions; the walker kernel walks every line
