@@ -368,8 +368,11 @@ bool walker_applies(const vp_ctx* c, int W) {
     // a CU holds per_cu walker workgroups at once (24 wave slots / waves per walker, LDS permitting); the batch lies
     // on the 256 CUs in layers of 256 workgroups and the launch takes as long as the fullest CU's layers
     const int per_cu = std::max(1, std::min(24 / std::max(1, nt), (int)(c->lds_limit / walker_lds_bytes(c))));
+    // (short spectra: more workgroups fit on a CU and more layers stay ahead of the launches -- C1 cut to 1400 pixels, 4
+    // tiles, 1024 walkers 22.0 vs 29.2 us; 2100 pixels, 6 tiles: 768 walkers 22.7 vs 30.1, 1024: 39.3 vs 33.5; 2800 pixels,
+    // 8 tiles: 768 walkers 26.4 vs 33.6, 1024: 38.0 vs 37.6)
     const int layers = (W + 255) / 256;
-    return layers <= std::min(per_cu, 2);
+    return layers <= per_cu && (layers <= 3 || layers <= per_cu - 2);
 }
 
 // (clusters: without their multipole records the members are ordinary lines -- a few more wing evaluations per pass
