@@ -322,7 +322,7 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
 // CU, so the launch time is a step function of the number of 256-workgroup layers: measured on C1 (us per pass,
 // walker kernel / prep + tile + finalize launches) 64: 18.2 / 22.3, 128: 18.3 / 23.5, 256: 18.3 / 24.9,
 // 320: 24.8 / 26.9, 384: 24.8 / 29.3, 512: 25.0 / 31.0, 640: 38.5 / 35.5, 768: 38.9 / 36.4, 1024: 47.3 / 43.1.
-// By default it is therefore used whenever the batch fits the CUs at once (at most two layers); larger batches keep
+// By default it is therefore used whenever the batch fits the CUs at once (two layers on C1); larger batches keep
 // the one-wave workgroups, whose slots the hardware refills one by one as tiles finish.  Instruments with multipole
 // clusters (>= 3 components of a transition) run it WITHOUT cluster records, their members as ordinary lines: forming
 // the records in the workgroup costs a long per-lane chain and scratch; measured on 4096 pixels, us per pass, walker
