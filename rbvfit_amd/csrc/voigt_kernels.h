@@ -569,8 +569,12 @@ constexpr int WALKER_THREADS_MAX = 1024; // walker_kernel: one wave per tile, up
 constexpr int FL_PAD = 10;        // LDS doubles after a tile's flux that the zero-padded taps may read
 // Diagnostic build (-DVP_STAMPS, scripts/walker_timeline.py): every wave of walker_kernel leaves the shader clock at its
 // phase boundaries in g_stamps[walker][wave][stage]; read back with vp_debug_read_stamps.  Not compiled otherwise.
+// Stages: 0 entry, 1 records ready (behind the first barrier), 2 end of phase A, 3 end of phase B, 4 end of LSF + chi^2,
+// 5 behind the last barrier, 6 start of phase B (tiles with line cores), 7 HW_ID | XCC_ID << 32 (where the wave runs),
+// 8 kernel arguments have arrived, 9 theta row has arrived, 10 record tasks issued, 11 stores drained and preloads back.
+// Ablation builds (timing only, results are wrong): -DVP_ABL_NOFAR / NOCORE / NOLSF drop the |x| >= 30 tiers, phase B, the LSF.
 #ifdef VP_STAMPS
-constexpr int STAMP_W = 1024, STAMP_WAVES = 16, STAMP_STAGES = 8;
+constexpr int STAMP_W = 1024, STAMP_WAVES = 16, STAMP_STAGES = 16;
 __device__ long long g_stamps[STAMP_W * STAMP_WAVES * STAMP_STAGES];
 #define VP_STAMP(stage) do { if (g_stamp_w >= 0 && g_stamp_w < STAMP_W && (threadIdx.x & 63) == 0) \
     g_stamps[(g_stamp_w * STAMP_WAVES + (int)(threadIdx.x >> 6)) * STAMP_STAGES + (stage)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -1012,6 +1016,9 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
 #pragma unroll
                     for (int r = 1; r < RB; ++r) xm = fmin(xm, fabs(x[r]));
                     if (VP_NONE_BELOW(xm, 30.0)) {        // the 1-FMA x is accurate enough out here
+#ifdef VP_ABL_NOFAR
+                        continue;
+#endif
                         if (VP_NONE_BELOW(xm, 100.0)) {
                             if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, K, tau);
                             else if (VP_NONE_BELOW(xm, 500.0)) wing_rb<3>(x, K, tau);
@@ -1116,6 +1123,9 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             }
             anyc = __ballot(anycore != 0u) != 0ull;
         }
+#ifdef VP_ABL_NOCORE
+        anyc = false;
+#endif
         if (anyc) {
             if (!daw_ready) {                        // staged only when some chunk needs the core series
 #ifndef VP_NO_PRIO
@@ -1176,6 +1186,9 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     //      reads at most 9 doubles past the last one).  Per output the taps are still accumulated in ascending order, so the result is
     //      bit-identical to the plain loop.
     double acc = 0.0;
+#ifdef VP_ABL_NOLSF
+    if (OUT == 0) { VP_STAMP(4); return fl[tid]; }
+#endif
     if (OUT != 2) {
         // blocks of 4 output pixels per lane (two pairs: ILP) while more than 2 per lane remain, then blocks of 2: the
         // tail of a 362-pixel tile is one 128-pixel block instead of a mostly masked 256-pixel one.  Same pixels per
@@ -1378,6 +1391,15 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     extern __shared__ double smem[];
     VP_STAMP_DECL
     VP_STAMP(0);
+#ifdef VP_STAMPS
+    {   // where the wave runs: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]) | XCC_ID << 32
+        unsigned int hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (g_stamp_w >= 0 && g_stamp_w < STAMP_W && (threadIdx.x & 63) == 0)
+            g_stamps[(g_stamp_w * STAMP_WAVES + (int)(threadIdx.x >> 6)) * STAMP_STAGES + 7] = (long long)hwid | ((long long)xcc << 32);
+    }
+#endif
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler knows it: the tile
                                                                    // geometry stays in SGPRs as in tile_kernel
@@ -1401,6 +1423,11 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     } else {
         thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
     }
+#ifdef VP_STAMPS
+    VP_STAMP(8);
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(thv) : "memory");
+    VP_STAMP(9);
+#endif
     const int ngrp = (T.L + 3) >> 2, ncl = CLUSTERS ? ((T.NCm + 63) >> 6) : 0;
     const int ntask = 1 + ngrp + ncl;              // task 0: box prior; then line groups; then cluster records
     for (int task = wid; task < ntask; task += nw) {
@@ -1420,6 +1447,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     const InstDev& I = ki == 0 ? I0 : (ki == 1 ? I1 : (ki == 2 ? I2 : I3));
     const int lt = ki == 0 ? wid : wid - tb.t[ki - 1];            // tile of its instrument
     const int p0 = lt * I.TP, nout = min(p0 + I.TP, I.P) - p0;
+    VP_STAMP(10);
     const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
     fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = g_exp2_64[lane];   // the wave's exp table (EXP_LDS_DOUBLES = 64 entries),
                                                                            // staged while it waits for the records anyway
@@ -1427,6 +1455,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     const bool daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(I.core_hint[lt]) != 0;
     if (daw_ready) dawson_to_lds(fl + I.span + FL_PAD + 4, lane, 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VP_STAMP(11);
     __syncthreads();
     VP_STAMP(1);
 #ifndef VP_NO_PRIO
