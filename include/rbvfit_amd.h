@@ -141,13 +141,16 @@ int vp_stretch_run(vp_ctx* ctx, int W, int D, double* pos, double* lnprob, int h
  * ensemble slice sampling with the differential move.  Per iteration the ensemble is split at random in two
  * halves; every walker of the active half slices along mu * 2.38/sqrt(2 D) * (X_l - X_m) (l != m from the other
  * half) with stepping-out and shrinking.  The ragged sets of still-active walkers are compacted ON the GPU: each
- * round is one lnprob batch of W/2 rows (active trial points first, the rest prior-rejected filler), and the
- * host only reads one word per group of rounds to learn whether the half-step is finished.
+ * round is one lnprob batch of slice_rows * W/2 rows ("slice_rows" option, 2 ... 8, default 2: W rows -- the next 2 ... 8
+ * trial points of every active walker first, the rest prior-rejected filler), and the host only reads one word per
+ * group of rounds to learn whether the half-step is finished.
  *   pos, lnprob, have_lnprob, seed, step0, chain, chain_lnprob: as in vp_stretch_run.  W even, 4 <= W <= 2048.
  *   mu         in: initial scale (zeus: 1.0), out: scale after the run.
  *   tune       != 0: adapt mu after every iteration (mu *= 2 n_expansions / (n_expansions + n_contractions)),
  *              and stop adapting after `patience` consecutive iterations with |ratio - 1| < tolerance
- *              (zeus: tolerance 0.05, patience 5); out: whether tuning is still on.
+ *              (zeus: tolerance 0.05, patience 5).  The value carries the tuning state from call to call, so that
+ *              run(n1) then run(n2) equals run(n1 + n2) while tuning is on: in, 1 + the number of consecutive
+ *              in-tolerance iterations so far (1 for a fresh run); out, the same, or 0 once tuning has stopped.
  *   maxsteps   cap on the stepping-out expansions per slice (zeus: 10000).
  *   mu_history (nsteps) host or NULL: mu after each iteration.
  *   n_evals    out (or NULL): lnprob evaluations spent (trial points), ADDED to the value passed in.

@@ -147,6 +147,7 @@ struct vp_multi {
     std::vector<vp_ctx*> ctx;
     std::mutex mu;
     std::string err;
+    bool broken = false;         // a setup call failed half-way and could not be undone: the contexts differ, every later call fails
 };
 
 namespace {
@@ -535,7 +536,7 @@ int check_batch_args(vp_ctx* c, int W, int D, const void* a, const void* b) {
 
 extern "C" {
 
-const char* vp_version(void) { return "rbvfit_amd 0.1.0 (gfx950, hip)"; }
+const char* vp_version(void) { return "rbvfit_amd 0.3.0 (gfx950, hip)"; }
 
 int vp_device_count(void) {
     int n = 0;
@@ -1149,7 +1150,8 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
     int* d_nact = st.widx + half;
     int* d_nan = d_nact + 1;
     vp::SliceCounters cn{d_nact, d_ll, d_ll + 1, d_ll + 2, d_nan, d_nact + 2, d_mu};
-    const double h_mu[4] = {*mu, 0.0, *tune ? 1.0 : 0.0, 0.0};
+    // `tune` carries the tuning state across calls: 0 off, n >= 1 on with n - 1 consecutive in-tolerance iterations so far
+    const double h_mu[4] = {*mu, *tune > 0 ? (double)(*tune - 1) : 0.0, *tune ? 1.0 : 0.0, 0.0};
     HIP_TRY(c, hipMemcpyAsync(d_pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_mu, h_mu, sizeof(h_mu), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync(d_ll, 0, 4 * sizeof(long long), s));
@@ -1222,7 +1224,7 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
     if (mu_history && nsteps > 0) HIP_TRY(c, hipMemcpyAsync(mu_history, d_muhist, (size_t)nsteps * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     *mu = h_mu_out[0];
-    *tune = h_mu_out[2] != 0.0 ? 1 : 0;
+    *tune = h_mu_out[2] != 0.0 ? 1 + (int)h_mu_out[1] : 0;
     if (n_evals) *n_evals += (int64_t)h_ll[0];
     return VP_OK;
 }
@@ -1342,11 +1344,44 @@ static int multi_fail(vp_multi* m, int i, int rc) {
     return rc;
 }
 
+static int multi_broken(vp_multi* m) {
+    m->err = "this vp_multi is unusable: an earlier vp_multi_set_bounds / vp_multi_add_instrument failed on one device and could not be undone on the others";
+    return VP_ESTATE;
+}
+
+// (internal) drop the instrument added last to one context: the undo step of vp_multi_add_instrument
+static int ctx_pop_instrument(vp_ctx* c) {
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->inst.empty()) return VP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    for (void* p : c->inst.back().allocs) hipFree(p);
+    c->inst.pop_back();
+    c->meta_dirty = true;
+    return VP_OK;
+}
+
 int vp_multi_set_bounds(vp_multi* m, int D, const double* lb, const double* ub) {
     if (!m) return VP_EINVAL;
     std::lock_guard<std::mutex> g(m->mu);
-    for (size_t i = 0; i < m->ctx.size(); ++i)
-        if (int rc = vp_set_bounds(m->ctx[i], D, lb, ub)) return multi_fail(m, (int)i, rc);
+    if (m->broken) return multi_broken(m);
+    // what the contexts hold now (they are kept identical), to put back should a later context fail
+    std::vector<double> old_lb, old_ub;
+    int oldD = 0;
+    {
+        vp_ctx* c0 = m->ctx[0];
+        std::lock_guard<std::mutex> g0(c0->mu);
+        oldD = c0->D; old_lb = c0->h_lb; old_ub = c0->h_ub;
+    }
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        const int rc = vp_set_bounds(m->ctx[i], D, lb, ub);
+        if (!rc) continue;
+        multi_fail(m, (int)i, rc);
+        for (size_t k = 0; k < i; ++k) {                 // undo on the contexts already changed
+            if (oldD <= 0 || vp_set_bounds(m->ctx[k], oldD, old_lb.data(), old_ub.data()) != VP_OK) m->broken = true;
+        }
+        return rc;
+    }
     return VP_OK;
 }
 
@@ -1357,36 +1392,53 @@ int vp_multi_add_instrument(vp_multi* m, int P, const double* wave, const double
                             int* inst_index) {
     if (!m) return VP_EINVAL;
     std::lock_guard<std::mutex> g(m->mu);
-    for (size_t i = 0; i < m->ctx.size(); ++i)
-        if (int rc = vp_add_instrument(m->ctx[i], P, wave, flux, inv_sigma2, log_inv_sigma2, L, lambda0, gamma, f, zfac, N_idx, b_idx,
-                                       v_idx, K, taps, lsf_mode, voigt_method, inst_index))
-            return multi_fail(m, (int)i, rc);
+    if (m->broken) return multi_broken(m);
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        const int rc = vp_add_instrument(m->ctx[i], P, wave, flux, inv_sigma2, log_inv_sigma2, L, lambda0, gamma, f, zfac, N_idx, b_idx,
+                                         v_idx, K, taps, lsf_mode, voigt_method, inst_index);
+        if (!rc) continue;
+        multi_fail(m, (int)i, rc);                       // (argument errors fail on the first context: nothing to undo)
+        for (size_t k = 0; k < i; ++k)
+            if (ctx_pop_instrument(m->ctx[k]) != VP_OK) m->broken = true;
+        return rc;
+    }
     return VP_OK;
 }
 
 int vp_multi_lnprob_batch(vp_multi* m, int W, int D, const double* theta, double* out) {
     if (!m) return VP_EINVAL;
     std::lock_guard<std::mutex> g(m->mu);
+    if (m->broken) return multi_broken(m);
     if (W < 0 || (W > 0 && (!theta || !out))) { m->err = "vp_multi_lnprob_batch: bad batch"; return VP_EINVAL; }
     const int G = (int)m->ctx.size();
     const int per = W > 0 ? (W + G - 1) / G : 0;
     std::vector<std::unique_lock<std::mutex>> locks;
-    int rc = VP_OK, started = 0;
+    std::vector<char> begun(G, 0);                     // whose batch is in flight (its pinned buffer exists and will be written)
+    int rc = VP_OK;
     for (int i = 0; i < G && !rc; ++i) {               // every block in flight before any wait
         const int lo = std::min(i * per, W), n = std::min(lo + per, W) - lo;
         vp_ctx* c = m->ctx[i];
         locks.emplace_back(c->mu);
-        ++started;
         if ((rc = check_batch_args(c, n, D, theta, out))) { multi_fail(m, i, rc); break; }
-        if (n > 0 && (rc = lnprob_host_begin(c, n, D, theta + (size_t)lo * D))) multi_fail(m, i, rc);
-    }
-    for (int i = 0; i < started; ++i) {                 // (also drains the blocks already enqueued when a later one failed)
-        const int lo = std::min(i * per, W), n = std::min(lo + per, W) - lo;
         if (n <= 0) continue;
-        const int rc2 = lnprob_host_end(m->ctx[i], n, D, out + lo);
-        if (rc2 && !rc) rc = multi_fail(m, i, rc2);
+        if ((rc = lnprob_host_begin(c, n, D, theta + (size_t)lo * D))) multi_fail(m, i, rc);
+        else begun[i] = 1;
     }
-    return rc;
+    // drain what was started (also when a later block failed); `out` is written only when every block succeeded
+    for (int i = 0; i < G; ++i) {
+        if (!begun[i]) continue;
+        vp_ctx* c = m->ctx[i];
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            if (!rc) { c->err = "hipStreamSynchronize failed"; rc = multi_fail(m, i, VP_EHIP); }
+        }
+    }
+    if (rc) return rc;
+    for (int i = 0; i < G; ++i) {
+        if (!begun[i]) continue;
+        const int lo = std::min(i * per, W), n = std::min(lo + per, W) - lo;
+        std::memcpy(out + lo, m->ctx[i]->h_pinned + (size_t)n * D, (size_t)n * sizeof(double));
+    }
+    return VP_OK;
 }
 
 void* vp_ctx_stream(const vp_ctx* c) { return c ? (void*)c->stream : nullptr; }

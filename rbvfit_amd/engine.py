@@ -242,7 +242,8 @@ class Engine:
                   patience: int = 5, maxsteps: int = 10000, seed: int = 0, step0: int = 0, store_chain: bool = True):
         """``nsteps`` iterations of ensemble slice sampling (zeus' differential move) on the GPU; the ragged
         active sets of the stepping-out / shrinking rounds are compacted in HBM.  Returns a dict: pos, lnprob,
-        chain, chain_lnprob (None when ``store_chain`` is False), mu, tune (still adapting?), mu_history, n_evals."""
+        chain, chain_lnprob (None when ``store_chain`` is False), mu, tune (still adapting?), tune_state (pass it back as
+        ``tune`` to continue the run: the patience counter travels with it), mu_history, n_evals."""
         self._guard()
         pos = np.array(pos, dtype=np.float64, order="C")
         if pos.ndim != 2:
@@ -255,7 +256,8 @@ class Engine:
         chain = np.empty((nsteps, W, D), dtype=np.float64) if store_chain else None
         clp = np.empty((nsteps, W), dtype=np.float64) if store_chain else None
         hist = np.empty(max(nsteps, 1), dtype=np.float64)
-        c_mu, c_tune, c_ne = C.c_double(float(mu)), C.c_int(1 if tune else 0), C.c_int64(0)
+        # tune: False / True, or the integer state a previous call returned in "tune_state" (1 + consecutive in-tolerance iterations)
+        c_mu, c_tune, c_ne = C.c_double(float(mu)), C.c_int(int(tune) if tune else 0), C.c_int64(0)
         rc = self._lib.vp_slice_run(self._ctx, W, D, _dp(pos), _dp(lp), 1 if have else 0, int(nsteps), C.byref(c_mu),
                                     C.byref(c_tune), float(tolerance), int(patience), int(maxsteps),
                                     C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint64(int(step0)),
@@ -266,7 +268,7 @@ class Engine:
             raise ValueError(msg.decode() if msg else "Log Probability returned NaN")
         self._check(rc)
         return dict(pos=pos, lnprob=lp, chain=chain, chain_lnprob=clp, mu=c_mu.value, tune=bool(c_tune.value),
-                    mu_history=hist[:nsteps], n_evals=int(c_ne.value))
+                    tune_state=int(c_tune.value), mu_history=hist[:nsteps], n_evals=int(c_ne.value))
 
     @property
     def last_launch_kind(self) -> str:

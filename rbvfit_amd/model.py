@@ -122,19 +122,37 @@ def tables_from_rbvfit(compiled) -> CompiledModelData:
                              getattr(d, "voigt_method", "wofz"))
 
 
+def mean_fwhm_pixels(FWHM_vel_kms: float, wave_obs_grid) -> float:
+    """FWHM in km/s -> mean FWHM in pixels of a wavelength grid (core/voigt_model.py:33-58): the mean over the grid
+    of lambda FWHM / c divided by ``np.gradient`` of the grid.  Same checks and messages as the reference."""
+    wave_obs_grid = np.asarray(wave_obs_grid)
+    if np.any(wave_obs_grid <= 0):
+        raise ValueError("Wavelength grid must be strictly positive.")
+    if len(wave_obs_grid) < 2:
+        raise ValueError("Wavelength grid must have at least two points.")
+    c_kms = 299792.458
+    delta_lambda = np.gradient(wave_obs_grid)
+    fwhm_lambda = wave_obs_grid * FWHM_vel_kms / c_kms
+    return float(np.mean(fwhm_lambda / delta_lambda))
+
+
 class VoigtModel:
     """Single-instrument model description.  ``FWHM`` is in pixels, as a string or float, or None
     for no LSF; ``kernel_taps`` supplies a tabulated LSF (the reference's 'COS' / CustomKernel
-    branch -> normalising 'extend' convolution).  ``normalize_kernel`` selects whether the Gaussian
-    taps are sum-normalised -- what ``Gaussian1DKernel(...).array`` holds under the astropy the
-    reference declares (>= 5.3.3, setup.cfg:30-37), hence the default -- or raw samples (astropy 4.x:
-    the version the golden fixtures and the SURVEY anchors were made with; tests and the synthetic
-    workloads pass ``normalize_kernel=False`` explicitly).  For FWHM '6.5' the two differ by
-    sum(taps) = 1 - 2.8e-5 on every pixel (trap T2)."""
+    branch -> normalising 'extend' convolution; ``FWHM='COS'`` itself needs linetools' tables, which
+    this package does not carry: pass their samples as ``kernel_taps``).
+
+    ``normalize_kernel``: whether the Gaussian taps are divided by their sum.  The default, False, is
+    what ``Gaussian1DKernel(...).array`` holds under astropy 4.3.1 -- the only astropy the reference
+    could be run with here, and the version every golden fixture and SURVEY anchor was made with, so the
+    default path of this class is the pinned one (``tests/golden/taps.npz``).  True gives the same samples
+    divided by their sum (pinned against the same fixture, ``tests/test_host_logic.py``) for an astropy
+    whose Gaussian kernels are sum-normalised; for FWHM '6.5' the two differ by sum(taps) = 1 - 2.8e-5
+    on every pixel (trap T2).  The engine takes taps as data either way."""
 
     def __init__(self, config: FitConfiguration, FWHM: Union[str, float, None] = "6.5",
                  voigt_method: str = "wofz", kernel_taps: Optional[Sequence[float]] = None,
-                 normalize_kernel: bool = True):
+                 normalize_kernel: bool = False):
         if voigt_method not in ("wofz", "fast"):
             raise ValueError(f"voigt_method must be one of ('wofz', 'fast'), got '{voigt_method}'")
         self.voigt_method = voigt_method
@@ -146,6 +164,10 @@ class VoigtModel:
         elif self.FWHM is None:
             self.taps, self.lsf_mode = None, L.LSF_NONE
         else:
+            if isinstance(self.FWHM, str) and self.FWHM.strip().upper() == "COS":
+                # core/voigt_model.py:448-460 builds this kernel from linetools' COS tables
+                raise ImportError("COS LSF requires linetools package; rbvfit_amd does not carry its tables -- "
+                                  "pass the tabulated LSF samples as kernel_taps=")
             self.taps = gaussian_taps(float(self.FWHM), normalize=normalize_kernel)
             self.lsf_mode = L.LSF_SCIPY_NEAREST
         # line order: system -> ion_group -> transition -> component   (voigt_model.py:391-401)

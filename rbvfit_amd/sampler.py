@@ -256,6 +256,7 @@ class DeviceSliceSampler:
         self.mu, self.maxsteps, self.tune = float(mu), int(maxsteps), bool(tune)
         self.tolerance, self.patience = float(tolerance), int(patience)
         self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0])
+        self._tune_state = 1                  # 1 + consecutive in-tolerance iterations: carried from call to call
         self.chain = None
         self.lnprobability = None
         self.nsteps = 0
@@ -266,10 +267,10 @@ class DeviceSliceSampler:
         pos = np.array(p0, dtype=np.float64)
         if pos.shape != (self.nwalkers, self.ndim):
             raise ValueError(f"initial state must have shape ({self.nwalkers}, {self.ndim})")
-        r = self.engine.slice_run(pos, nsteps, lnprob=lnprob0, mu=self.mu, tune=self.tune, tolerance=self.tolerance,
+        r = self.engine.slice_run(pos, nsteps, lnprob=lnprob0, mu=self.mu, tune=self._tune_state if self.tune else 0, tolerance=self.tolerance,
                                   patience=self.patience, maxsteps=self.maxsteps, seed=self.seed, step0=self.nsteps,
                                   store_chain=store)
-        self.mu, self.tune = r["mu"], r["tune"]
+        self.mu, self.tune, self._tune_state = r["mu"], r["tune"], r["tune_state"]
         self.mu_history.extend(r["mu_history"].tolist())
         self.n_lnprob_evals += r["n_evals"]
         if store:

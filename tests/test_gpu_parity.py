@@ -257,3 +257,47 @@ def test_multi_context_sharding_from_one_process():
                 m._check(m._lib.vp_multi_lnprob_batch(m._m, 3, 5, bad.ctypes.data_as(dp), buf.ctypes.data_as(dp)))
     with pytest.raises(rbvfit_amd.RbvfitAmdError):
         rbvfit_amd.MultiEngine([0, 99])
+
+
+def test_multi_context_errors_on_a_fresh_object_leave_the_output_alone():
+    """Error paths of vp_multi_lnprob_batch before any batch has run (no pinned staging buffer exists yet): lnprob with
+    bounds but no instrument, and a wrong D, return the error of the failing slot -- no crash -- and do not touch `out`;
+    an instrument that one context refuses is taken back from the contexts that had accepted it."""
+    import ctypes as C
+    import rbvfit_amd
+    from helpers import fixture_instruments
+    z = load_golden("c0_mgii")
+    dp = C.POINTER(C.c_double)
+    with rbvfit_amd.MultiEngine([0, 0]) as m:
+        m.set_bounds(z["lb"], z["ub"])
+        th = np.ascontiguousarray(z["thetas"][:8])
+        out = np.full(8, 123.0)
+        with pytest.raises(rbvfit_amd.RbvfitAmdError, match="device slot 0.*no instrument"):
+            m._check(m._lib.vp_multi_lnprob_batch(m._m, 8, th.shape[1], th.ctypes.data_as(dp), out.ctypes.data_as(dp)))
+        assert np.all(out == 123.0)
+        inst = fixture_instruments(z)[0]
+        g = lambda k: z[f"{inst}__{k}"]
+        args = (g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"), g("f"), g("zfac"), g("N_idx"),
+                g("b_idx"), g("v_idx"))
+        kw = dict(taps=g("taps"), lsf_mode=int(g("lsf_mode")), voigt_method=int(g("voigt_method")))
+        with pytest.raises(rbvfit_amd.RbvfitAmdError):                  # an even number of taps: refused by the first context
+            m.add_instrument(*args, **dict(kw, taps=g("taps")[:-1]))
+        m.add_instrument(*args, **kw)
+        bad = np.zeros((3, 5))
+        with pytest.raises(rbvfit_amd.RbvfitAmdError, match="device slot 0.*D=5"):
+            m._check(m._lib.vp_multi_lnprob_batch(m._m, 3, 5, bad.ctypes.data_as(dp), out.ctypes.data_as(dp)))
+        assert np.all(out == 123.0)
+        with engine_from_fixture(z) as one:
+            np.testing.assert_array_equal(m.lnprob(th), one.lnprob(th))
+        # a failure on the SECOND context is undone on the first: the two stay in step
+        c1 = C.c_void_p(m._lib.vp_multi_ctx(m._m, 1))
+        one_ctx_only = m._lib.vp_add_instrument
+        n0 = m._lib.vp_num_instruments(C.c_void_p(m._lib.vp_multi_ctx(m._m, 0)))
+        m._lib.vp_set_option(c1, b"lds_pad", 10 ** 9)            # context 1 will refuse the next instrument (LDS budget)
+        with pytest.raises(rbvfit_amd.RbvfitAmdError, match="device slot 1"):
+            m.add_instrument(*args, **kw)
+        m._lib.vp_set_option(c1, b"lds_pad", 0)
+        assert m._lib.vp_num_instruments(C.c_void_p(m._lib.vp_multi_ctx(m._m, 0))) == n0
+        assert m._lib.vp_num_instruments(c1) == n0
+        with engine_from_fixture(z) as one:
+            np.testing.assert_array_equal(m.lnprob(th), one.lnprob(th))

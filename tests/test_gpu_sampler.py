@@ -370,6 +370,26 @@ def test_device_slice_sampler_equals_an_independent_host_replay(W, nsteps):
     np.testing.assert_array_equal(b["chain"][0], dev["chain"][5])      # (the patience counter restarts: compare the first step)
 
 
+def test_device_slice_sampler_split_runs_carry_the_tuning_state():
+    """run(6) then run(6) is run(12) bit for bit WHILE mu is being tuned: the count of consecutive in-tolerance iterations
+    travels from call to call (vp_slice_run's `tune` in/out), so tuning switches off at the same iteration either way."""
+    from rbvfit_amd.sampler import DeviceSliceSampler
+    wl = _workload()
+    eng, p0 = wl.engine, wl.thetas
+    kw = dict(seed=11, tolerance=0.6, patience=8)            # loose tolerance: the streak builds up across the split
+    one = DeviceSliceSampler(48, 6, eng, **kw)
+    one.run_mcmc(p0, 12)
+    two = DeviceSliceSampler(48, 6, eng, **kw)
+    two.run_mcmc(p0, 6)
+    assert two.tune and two._tune_state > 1                  # (the split falls inside a streak)
+    two.run_mcmc(two.chain[-1], 6, lnprob0=two.lnprobability[-1])
+    assert not one.tune and not two.tune                     # both switched tuning off ...
+    np.testing.assert_array_equal(one.mu_history, two.mu_history)      # ... at the same iteration
+    np.testing.assert_array_equal(one.chain, two.chain)
+    np.testing.assert_array_equal(one.lnprobability, two.lnprobability)
+    assert one.n_lnprob_evals == two.n_lnprob_evals
+
+
 def test_device_slice_sampler_distribution_and_vfit_switch():
     from rbvfit_amd.model import FitConfiguration, VoigtModel
     from rbvfit_amd.sampler import DeviceSliceSampler

@@ -8,7 +8,7 @@ import pytest
 from conftest import load_golden
 from rbvfit_amd import atomic, LSF_SCIPY_NEAREST, LSF_ASTROPY_EXTEND, LSF_NONE
 from rbvfit_amd.lsf import gaussian_taps
-from rbvfit_amd.model import FitConfiguration, VoigtModel, tables_from_rbvfit
+from rbvfit_amd.model import FitConfiguration, VoigtModel, mean_fwhm_pixels, tables_from_rbvfit
 from rbvfit_amd.vfit import set_bounds, vfit
 from rbvfit_amd.dist import shard_bounds
 from rbvfit_amd.sampler import StretchMoveSampler, initialize_walkers
@@ -66,6 +66,49 @@ def test_kernel_branches():
     assert abs(gaussian_taps(6.5).sum() - 0.999972) < 1e-6          # trap T2: raw taps are not normalised
     with pytest.raises(ValueError):
         _model(MGII, "6.5", voigt_method="nope")
+
+
+def test_default_taps_are_the_pinned_ones_and_normalised_taps_are_their_quotient():
+    """VoigtModel's default kernel path (no normalize_kernel argument) is the one the golden fixtures pin: the reference's
+    own Gaussian1DKernel(...).array (astropy 4.3.1, tests/golden/taps.npz).  normalize_kernel=True is pinned against the
+    same fixture: taps / sum(taps)."""
+    z = load_golden("taps")
+    cfg = FitConfiguration()
+    cfg.add_system(0.348, "MgII", [2796.35, 2803.53], 2)
+    for key in z.files:
+        fw = key[len("fwhm_"):]
+        ref = np.asarray(z[key], dtype=np.float64)
+        m = VoigtModel(cfg, FWHM=fw)                                   # the default
+        assert m.lsf_mode == LSF_SCIPY_NEAREST and m.taps.size == ref.size
+        np.testing.assert_allclose(m.taps, ref, rtol=5e-16, atol=0)
+        mn = VoigtModel(cfg, FWHM=fw, normalize_kernel=True)
+        np.testing.assert_allclose(mn.taps, ref / ref.sum(), rtol=5e-16, atol=0)
+        assert abs(mn.taps.sum() - 1.0) < 1e-15
+
+
+def test_mean_fwhm_pixels_matches_the_reference():
+    """core/voigt_model.py:33-58 on a linear, a log-spaced and an irregular grid (values made by the reference itself,
+    tests/golden/make_golden_host.py)."""
+    z = load_golden("host_helpers")
+    for name in ("linear", "loglam", "irregular"):
+        got = [mean_fwhm_pixels(float(f), z[f"{name}__wave"]) for f in z["fwhm_kms"]]
+        np.testing.assert_allclose(got, z[f"{name}__pixels"], rtol=1e-14, atol=0)
+    with pytest.raises(ValueError, match="strictly positive"):
+        mean_fwhm_pixels(10.0, np.array([0.0, 1.0, 2.0]))
+    with pytest.raises(ValueError, match="at least two points"):
+        mean_fwhm_pixels(10.0, np.array([1000.0]))
+
+
+def test_cos_lsf_points_at_kernel_taps():
+    cfg = FitConfiguration()
+    cfg.add_system(0.0, "SiII", [1190.4158], 1)
+    with pytest.raises(ImportError, match="kernel_taps"):
+        VoigtModel(cfg, FWHM="COS")
+    cfg2 = FitConfiguration(FWHM="COS")                                # (FWHM through the configuration, as the reference allows)
+    cfg2.add_system(0.0, "SiII", [1190.4158], 1)
+    with pytest.raises(ImportError, match="linetools"):
+        VoigtModel(cfg2)
+    assert VoigtModel(cfg, FWHM="COS", kernel_taps=[0.2, 0.6, 0.2]).lsf_mode == LSF_ASTROPY_EXTEND
 
 
 def test_atomic_lookup_mirrors_rb_setline():
