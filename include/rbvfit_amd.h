@@ -202,6 +202,16 @@ int vp_multi_add_instrument(vp_multi* m, int P, const double* wave, const double
                             const int32_t* v_idx, int K, const double* taps, int lsf_mode, int voigt_method,
                             int* inst_index);
 int vp_multi_lnprob_batch(vp_multi* m, int W, int D, const double* theta, double* out);
+
+/* vp_stretch_run for ONE ensemble sharded over the contexts of `m` (BASELINE config 4; the reference fans one ensemble over
+ * its workers, vfit_mcmc.py:425-440, 536-540): every context holds the whole ensemble, proposes / evaluates / accepts its
+ * block of ceil(W/2 / G) rows of the active half and writes the rows it moved into every replica through peer-mapped
+ * pointers ((D + 1) doubles per moved walker); half-steps are ordered by events between the contexts' streams, the host
+ * does not wait until the call ends (or a chain chunk is copied out).  Arguments, results and the chain are those of
+ * vp_stretch_run FOR ANY G, bit for bit: the draws are keyed by the walker's index in the whole ensemble and every block is
+ * evaluated with the launch structure the whole half-ensemble would get on one context.  At most 8 contexts. */
+int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
+                         uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted);
 const char* vp_multi_last_error(const vp_multi* m);
 
 /* The context's own stream (a hipStream_t, created non-blocking): what hip_stream == NULL selects in the

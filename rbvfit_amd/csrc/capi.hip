@@ -135,6 +135,8 @@ struct vp_ctx {
     double* d_scratch = nullptr;
     size_t scratch_bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    int policy_W = 0;            // > 0: the launch structure of a batch is chosen as for THIS many rows (a block of a larger batch
+                                 // that other contexts share: same structure, hence the same bits, as the whole batch on one context)
     int last_kind = 0;           // launch structure of the last lnprob batch: 0 prep + tile (+ finalize), 1 walker_kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -147,6 +149,8 @@ struct vp_multi {
     std::vector<vp_ctx*> ctx;
     std::mutex mu;
     std::string err;
+    bool no_peer = false;        // some pair of devices cannot map each other's memory: no sharded device-resident sampler
+    std::vector<hipEvent_t> ev;  // one per context: the half-step barrier of vp_multi_stretch_run
     bool broken = false;         // a setup call failed half-way and could not be undone: the contexts differ, every later call fails
 };
 
@@ -431,7 +435,8 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     const bool prof = c->profiling;
     size_t m0 = prof ? prof_mark(c, s) : 0;
     c->last_kind = 0;
-    if (walker_applies(c, W)) {
+    const int Wp = c->policy_W > 0 ? c->policy_W : W;       // rows the launch structure is chosen for
+    if (walker_applies(c, Wp)) {
         c->last_kind = 1;
         launch_walker(c, W, d_theta, d_out, s);
         if (prof) {
@@ -445,7 +450,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     // tiles instead (twice the workgroups, half the per-wave latency): measured better up to 384
     // walkers x 12 tiles (30.2 vs 31.1 us), equal at 448, worse at 512 (256 CUs x 4 SIMDs x 6 waves =
     // 6144 slots).
-    int sel = ((long)W * c->total_tiles_g[0] <= 4800) ? 1 : 0;
+    int sel = ((long)Wp * c->total_tiles_g[0] <= 4800) ? 1 : 0;
     if (c->tune.geom >= 0) sel = c->tune.geom ? 1 : 0;
     const int ntot = c->total_tiles_g[sel];
     // Final reduction (bit-identical either way, see tile_kernel): fused into the tile kernel -- the
@@ -453,7 +458,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     // its own (one lane per walker) once the batch fills them, where the ticket's L2 round trips at the end of
     // every tile wave cost more than a launch.  Measured on C1 (us per pass, own launch / ticket): 256
     // walkers 26.5 / 26.7, 512: 32.3 / 33.0-33.9, 2048: 88.9 / 92.5, 8192: 314 / 329.
-    int fmode = ((long)W * c->total_tiles_g[0] < 6144) ? 1 : 0;
+    int fmode = ((long)Wp * c->total_tiles_g[0] < 6144) ? 1 : 0;
     if (c->tune.finalize >= 0) fmode = c->tune.finalize ? 1 : 0;      // 0: own launch, 1: ticket
     const bool fused = fmode != 0;
     const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw,
@@ -475,7 +480,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         // when the instrument is added); the crossover sits near 2e5 covered (walker, block, item) triples: C2 at 256
         // walkers (0.195e6) 72.7 / 71.5 us, the 40-line FeII fit at 1024 walkers (0.17e6) 164.9 / 161.1, the 20-line one
         // at 1024 (0.09e6) 90.4 / 93.2.
-        const bool ff_pays = c->tune.farfield > 0 || in.ff_cover * (double)W * geom.ntiles * geom.ff_nblk * in.ff_items >= 2.0e5;
+        const bool ff_pays = c->tune.farfield > 0 || in.ff_cover * (double)Wp * geom.ntiles * geom.ff_nblk * in.ff_items >= 2.0e5;
         double* ff = (in.ff_on && c->d_ff && ff_pays) ? c->d_ff : nullptr;
         if (ff) {                                        // the blocks' far-field expansions from the records just made
             c->last_kind = 2;
@@ -1324,12 +1329,24 @@ int vp_multi_create(vp_multi** out, int n_devices, const int* device_ids) {
         }
         m->ctx.push_back(c);
     }
+    // the contexts write into each other's ensembles (vp_multi_stretch_run): peer access between distinct devices
+    for (vp_ctx* a : m->ctx)
+        for (vp_ctx* b : m->ctx)
+            if (a->device != b->device && hipSetDevice(a->device) == hipSuccess) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(b->device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) m->no_peer = true;
+                (void)hipGetLastError();
+            }
     *out = m;
     return VP_OK;
 }
 
 int vp_multi_destroy(vp_multi* m) {
     if (!m) return VP_OK;
+    for (size_t i = 0; i < m->ev.size(); ++i) {
+        hipSetDevice(m->ctx[i]->device);
+        hipEventDestroy(m->ev[i]);
+    }
     for (vp_ctx* c : m->ctx) vp_ctx_destroy(c);
     delete m;
     return VP_OK;
@@ -1439,6 +1456,187 @@ int vp_multi_lnprob_batch(vp_multi* m, int W, int D, const double* theta, double
         std::memcpy(out + lo, m->ctx[i]->h_pinned + (size_t)n * D, (size_t)n * sizeof(double));
     }
     return VP_OK;
+}
+
+// All G streams wait for all G streams: G event records + G (G - 1) stream waits, no host synchronisation.
+static int multi_barrier(vp_multi* m) {
+    const int G = (int)m->ctx.size();
+    for (int g = 0; g < G; ++g) {
+        vp_ctx* c = m->ctx[g];
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipEventRecord(m->ev[g], c->stream));
+    }
+    for (int g = 0; g < G; ++g) {
+        vp_ctx* c = m->ctx[g];
+        HIP_TRY(c, hipSetDevice(c->device));
+        for (int h = 0; h < G; ++h)
+            if (h != g) HIP_TRY(c, hipStreamWaitEvent(c->stream, m->ev[h], 0));
+    }
+    return VP_OK;
+}
+
+// One ensemble, G device contexts (BASELINE config 4: "2048 zeus walkers sharded over 8 GPUs"; vfit_mcmc.py:425-440,
+// 536-540 fans ONE ensemble over its workers): see csrc/sampler_kernels.h.  Per half-step every context runs its block of
+// the active half -- one walker_kernel launch where vp_stretch_run would use one for the whole half, else propose ->
+// lnprob launches -> accept -- with the launch structure chosen as for the whole half (policy_W), so every row gets
+// the bits a single context gives it; then the event barrier.  Chain: replica 0 keeps it.
+int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
+                         uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted) {
+    if (!m) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(m->mu);
+    if (m->broken) return multi_broken(m);
+    const int G = (int)m->ctx.size();
+    if (G > vp::MAX_REPLICAS) { m->err = "vp_multi_stretch_run: at most " + std::to_string(vp::MAX_REPLICAS) + " device contexts"; return VP_EINVAL; }
+    if (m->no_peer) { m->err = "vp_multi_stretch_run: the devices cannot map each other's memory (no peer access)"; return VP_ESTATE; }
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (int i = 0; i < G; ++i) locks.emplace_back(m->ctx[i]->mu);
+    int rc;
+    for (int i = 0; i < G; ++i)
+        if ((rc = check_batch_args(m->ctx[i], W, D, pos, lnprob))) return multi_fail(m, i, rc);
+    vp_ctx* c0 = m->ctx[0];
+    if (W < 2 || (W & 1)) { c0->err = "vp_multi_stretch_run: the number of walkers must be even and >= 2"; return multi_fail(m, 0, VP_EINVAL); }
+    if (nsteps < 0 || !(a > 1.0)) { c0->err = "vp_multi_stretch_run: nsteps must be >= 0 and a > 1"; return multi_fail(m, 0, VP_EINVAL); }
+    if ((chain == nullptr) != (chain_lnprob == nullptr)) { c0->err = "vp_multi_stretch_run: chain and chain_lnprob go together"; return multi_fail(m, 0, VP_EINVAL); }
+    if (have_lnprob)
+        for (int w = 0; w < W; ++w)
+            if (lnprob[w] != lnprob[w]) { c0->err = "vp_multi_stretch_run: the initial lnprob holds NaN (Probability function returned NaN)"; return multi_fail(m, 0, VP_ENAN); }
+    if ((int)m->ev.size() != G) {
+        for (int i = (int)m->ev.size(); i < G; ++i) {
+            hipEvent_t e;
+            if (hipSetDevice(m->ctx[i]->device) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                m->ctx[i]->err = "hipEventCreate failed"; return multi_fail(m, i, VP_EHIP);
+            }
+            m->ev.push_back(e);
+        }
+    }
+    const int half = W / 2, per = (half + G - 1) / G;
+    // device state per context: pos (W,D) | lp (W) | prop (per,D) | lp_new (per) | zz (per) | [chain chunk: replica 0] ; nacc (W) | nanflag
+    const size_t row = (size_t)W * (D + 1);
+    const size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
+    struct Dev { double *pos, *lp, *prop, *lpnew, *zz, *chain; long long* nacc; int* nan; };
+    std::vector<Dev> dv(G);
+    for (int i = 0; i < G; ++i) {
+        vp_ctx* c = m->ctx[i];
+#define MTRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e__); return multi_fail(m, i, VP_EHIP); } } while (0)
+        MTRY(hipSetDevice(c->device));
+        if ((rc = ensure_workspace(c, std::max(W, per)))) return multi_fail(m, i, rc);
+        const size_t nd = (size_t)W * D + W + (size_t)per * D + 2 * (size_t)per + (i == 0 ? chunk * row : 0);
+        if ((rc = ensure_scratch(c, nd * sizeof(double) + (size_t)W * sizeof(long long) + 64))) return multi_fail(m, i, rc);
+        Dev& d = dv[i];
+        d.pos = c->d_scratch; d.lp = d.pos + (size_t)W * D; d.prop = d.lp + W; d.lpnew = d.prop + (size_t)per * D;
+        d.zz = d.lpnew + per; d.chain = d.zz + per;
+        d.nacc = reinterpret_cast<long long*>(d.chain + (i == 0 ? chunk * row : 0));
+        d.nan = reinterpret_cast<int*>(d.nacc + W);
+        MTRY(hipMemcpyAsync(d.pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        MTRY(hipMemsetAsync(d.nacc, 0, (size_t)W * sizeof(long long) + sizeof(int), c->stream));
+        if (have_lnprob) MTRY(hipMemcpyAsync(d.lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        else {
+            // every replica evaluates the whole start state itself (once per run; the same launches as vp_stretch_run's)
+            c->policy_W = 0;
+            if ((rc = enqueue_lnprob(c, W, d.pos, d.lp, c->stream))) return multi_fail(m, i, rc);
+            hipLaunchKernelGGL(vp::nan_flag_kernel, dim3((W + 255) / 256), dim3(256), 0, c->stream, d.lp, W, d.nan);
+        }
+    }
+    if (!have_lnprob) {
+        int h_nan0 = 0;
+        vp_ctx* c = c0; const int i = 0;
+        MTRY(hipSetDevice(c->device));
+        MTRY(hipMemcpyAsync(&h_nan0, dv[0].nan, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        MTRY(hipStreamSynchronize(c->stream));
+        if (h_nan0) { c0->err = "vp_multi_stretch_run: the initial lnprob holds NaN (Probability function returned NaN)"; return multi_fail(m, 0, VP_ENAN); }
+    }
+    vp::Replicas R{};
+    R.n = G;
+    for (int i = 0; i < G; ++i) { R.pos[i] = dv[i].pos; R.lp[i] = dv[i].lp; }
+    const int thr = 64;
+    auto finish = [&](int code) { for (int i = 0; i < G; ++i) m->ctx[i]->policy_W = 0; return code; };
+    if ((rc = multi_barrier(m))) return finish(multi_fail(m, 0, rc));             // every replica's start state is in place
+    for (int done = 0; done < nsteps;) {
+        const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
+        for (int it = 0; it < n; ++it) {
+            const uint64_t step = step0 + (uint64_t)(done + it);
+            for (int h = 0; h < 2; ++h) {
+                const int s0 = h ? half : 0, cc0 = h ? 0 : half;
+                for (int i = 0; i < G; ++i) {
+                    vp_ctx* c = m->ctx[i];
+                    const int k0 = std::min(i * per, half), nk = std::min(k0 + per, half) - k0;
+                    if (nk <= 0) continue;
+                    MTRY(hipSetDevice(c->device));
+                    c->policy_W = half;
+                    const Dev& d = dv[i];
+                    // (the choice vp_stretch_run makes for the whole half)
+                    const bool one_launch = !c->tune.no_fused_accept && c->tune.walker != 0 && walker_applies(c, half) &&
+                                            (c->inst[0].dev.NCm == 0 || !c->tune.walker_clusters);
+                    if (one_launch) {
+                        vp::StretchArgs sa{};
+                        sa.pos = d.pos; sa.lp = d.lp; sa.nacc = d.nacc; sa.nanflag = d.nan;
+                        sa.chain_pos = nullptr; sa.chain_lp = nullptr;
+                        sa.a = a; sa.seed = seed; sa.step = step; sa.s0 = s0 + k0; sa.c0 = cc0; sa.nC = half; sa.half = h;
+                        sa.rep = R;
+                        launch_walker_stretch(c, nk, sa, c->stream);
+                    } else {
+                        hipLaunchKernelGGL(vp::stretch_propose_block_kernel, dim3((nk + thr - 1) / thr), dim3(thr), 0, c->stream, d.pos, D, s0,
+                                           half, cc0, half, a, seed, step, h, k0, nk, d.prop, d.zz);
+                        if ((rc = enqueue_lnprob(c, nk, d.prop, d.lpnew, c->stream))) return finish(multi_fail(m, i, rc));
+                        hipLaunchKernelGGL(vp::stretch_accept_block_kernel, dim3((nk + thr - 1) / thr), dim3(thr), 0, c->stream, d.lp, R,
+                                           d.prop, d.lpnew, d.zz, D, s0, k0, nk, seed, step, h, d.nacc, d.nan);
+                    }
+                    MTRY(hipGetLastError());
+                }
+                if ((rc = multi_barrier(m))) return finish(multi_fail(m, 0, rc));
+            }
+            if (chain) {
+                vp_ctx* c = c0; const int i = 0;
+                MTRY(hipSetDevice(c->device));
+                MTRY(hipMemcpyAsync(dv[0].chain + (size_t)it * W * D, dv[0].pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                MTRY(hipMemcpyAsync(dv[0].chain + chunk * (size_t)W * D + (size_t)it * W, dv[0].lp, (size_t)W * sizeof(double),
+                                    hipMemcpyDeviceToDevice, c->stream));
+                // nobody writes into replica 0 (the next half-step's moved rows) before this snapshot is taken
+                MTRY(hipEventRecord(m->ev[0], c->stream));
+                for (int j = 1; j < G; ++j) {
+                    vp_ctx* cj = m->ctx[j];
+                    if (hipSetDevice(cj->device) != hipSuccess || hipStreamWaitEvent(cj->stream, m->ev[0], 0) != hipSuccess) {
+                        cj->err = "hipStreamWaitEvent failed"; return finish(multi_fail(m, j, VP_EHIP));
+                    }
+                }
+            }
+        }
+        if (chain) {
+            vp_ctx* c = c0; const int i = 0;
+            MTRY(hipSetDevice(c->device));
+            MTRY(hipMemcpyAsync(chain + (size_t)done * W * D, dv[0].chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            MTRY(hipMemcpyAsync(chain_lnprob + (size_t)done * W, dv[0].chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
+                                hipMemcpyDeviceToHost, c->stream));
+            MTRY(hipStreamSynchronize(c->stream));
+            // (the other replicas must not run ahead into the chunk buffer's next use: they only ever wait on events of
+            //  kernels, and replica 0's next kernels are enqueued behind these copies on its stream)
+        }
+        done += n;
+    }
+    // results: the ensemble from replica 0, every walker's acceptance count from the context that moved it, NaN flags from all
+    int any_nan = 0;
+    std::vector<long long> h_nacc(W);
+    for (int i = 0; i < G; ++i) {
+        vp_ctx* c = m->ctx[i];
+        MTRY(hipSetDevice(c->device));
+        int h_nan = 0;
+        MTRY(hipMemcpyAsync(&h_nan, dv[i].nan, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        MTRY(hipMemcpyAsync(h_nacc.data(), dv[i].nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+        if (i == 0) {
+            MTRY(hipMemcpyAsync(pos, dv[0].pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            MTRY(hipMemcpyAsync(lnprob, dv[0].lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        MTRY(hipStreamSynchronize(c->stream));
+        any_nan |= h_nan;
+        if (naccepted) {
+            const int k0 = std::min(i * per, half), nk = std::min(k0 + per, half) - k0;
+            for (int hh = 0; hh < 2; ++hh)
+                for (int k = k0; k < k0 + nk; ++k) naccepted[hh * half + k] += (int64_t)h_nacc[hh * half + k];
+        }
+    }
+#undef MTRY
+    if (any_nan) { c0->err = "vp_multi_stretch_run: Probability function returned NaN"; return finish(multi_fail(m, 0, VP_ENAN)); }
+    return finish(VP_OK);
 }
 
 void* vp_ctx_stream(const vp_ctx* c) { return c ? (void*)c->stream : nullptr; }

@@ -122,6 +122,61 @@ __global__ __launch_bounds__(1024) void stretch_accept_propose_kernel(
     stretch_propose(threadIdx.x, pos, D, nx.s0, nx.nS, nx.c0, nx.nC, a, seed, nx.step, nx.half, prop, zz);
 }
 
+// ---- one ensemble sharded over G device contexts (vp_multi_stretch_run) -------------------------------------------
+// Every context holds the WHOLE ensemble (positions, lnprob); of the active half it proposes, evaluates and accepts
+// only its block of rows [k0, k0 + nk), and writes the rows it moved into EVERY replica (its own included) -- plain
+// stores through peer-mapped pointers, (D + 1) doubles per moved walker; the host orders the half-steps with events.
+// The draws are keyed by the walker's index in the whole ensemble, so the chain does not depend on G.
+constexpr int MAX_REPLICAS = 8;
+struct Replicas { double* pos[MAX_REPLICAS]; double* lp[MAX_REPLICAS]; int n; };
+
+__global__ void stretch_propose_block_kernel(const double* __restrict__ pos, int D, int s0, int nS, int c0, int nC, double a,
+                                             uint64_t seed, uint64_t step, int half, int k0, int nk,
+                                             double* __restrict__ prop, double* __restrict__ zz) {
+    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kk >= nk) return;
+    (void)nS;
+    const int k = k0 + kk;
+    const Philox4 r = draw(seed, step, half, s0 + k, 0u);
+    const double u1 = u01(r.v[0], r.v[1]), u2 = u01(r.v[2], r.v[3]);
+    const double t = (a - 1.0) * u1 + 1.0;
+    const double z = t * t / a;
+    int j = (int)(u2 * (double)nC);
+    j = j < nC - 1 ? j : nC - 1;
+    const double* __restrict__ x = pos + (size_t)(s0 + k) * D;
+    const double* __restrict__ c = pos + (size_t)(c0 + j) * D;
+    double* __restrict__ y = prop + (size_t)kk * D;
+    for (int d = 0; d < D; ++d) y[d] = c[d] - (c[d] - x[d]) * z;       // (stretch_propose's arithmetic)
+    zz[kk] = z;
+}
+
+// accept / reject of the block (stretch_accept's arithmetic); moved rows go to every replica
+__global__ void stretch_accept_block_kernel(const double* __restrict__ lp_own, Replicas R, const double* __restrict__ prop,
+                                            const double* __restrict__ lp_new, const double* __restrict__ zz, int D, int s0,
+                                            int k0, int nk, uint64_t seed, uint64_t step, int half,
+                                            long long* __restrict__ nacc, int* __restrict__ nanflag) {
+    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kk >= nk) return;
+    const int w = s0 + k0 + kk;
+    const double ln = lp_new[kk];
+    if (ln != ln) {
+        atomicExch(nanflag, 1);
+        return;
+    }
+    const Philox4 r = draw(seed, step, half, w, 1u);
+    const double u = u01(r.v[0], r.v[1]);
+    const double lnq = (double)(D - 1) * log(zz[kk]) + ln - lp_own[w];
+    if (log(u) < lnq) {
+        const double* __restrict__ y = prop + (size_t)kk * D;
+        for (int rr = 0; rr < R.n; ++rr) {
+            double* __restrict__ x = R.pos[rr] + (size_t)w * D;
+            for (int d = 0; d < D; ++d) x[d] = y[d];
+            R.lp[rr][w] = ln;
+        }
+        nacc[w] += 1;
+    }
+}
+
 // Flags a NaN in a lnprob vector (the initial state of a run: emcee and the host sampler raise on it).
 __global__ void nan_flag_kernel(const double* __restrict__ lp, int W, int* __restrict__ nanflag) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;

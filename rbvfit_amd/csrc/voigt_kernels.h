@@ -1348,6 +1348,8 @@ struct StretchArgs {
     double a;              // stretch scale
     uint64_t seed, step;
     int s0, c0, nC, half;  // active rows [s0, s0 + gridDim.x), complementary rows [c0, c0 + nC)
+    Replicas rep;          // rep.n > 0 (vp_multi_stretch_run): moved rows are written to every replica of the ensemble
+                           // (this context's own among them) instead of pos / lp alone
 };
 
 struct WalkerArgs {
@@ -1518,8 +1520,16 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             accept = log(u01(r1.v[0], r1.v[1])) < lnq;
         }
         if (accept) {
-            if (lane < A.D) S.pos[(size_t)ws * A.D + lane] = y;
-            if (lane == 0) { S.lp[ws] = lnp; S.nacc[ws] += 1; }
+            if (S.rep.n > 0) {
+                for (int rr = 0; rr < S.rep.n; ++rr) {
+                    if (lane < A.D) S.rep.pos[rr][(size_t)ws * A.D + lane] = y;
+                    if (lane == 0) S.rep.lp[rr][ws] = lnp;
+                }
+                if (lane == 0) S.nacc[ws] += 1;
+            } else {
+                if (lane < A.D) S.pos[(size_t)ws * A.D + lane] = y;
+                if (lane == 0) { S.lp[ws] = lnp; S.nacc[ws] += 1; }
+            }
         }
         if (S.chain_pos) {
             if (lane < A.D) S.chain_pos[(size_t)ws * A.D + lane] = accept ? y : x;

@@ -387,3 +387,30 @@ class MultiEngine:
         out = np.empty(th.shape[0], dtype=np.float64)
         self._check(self._lib.vp_multi_lnprob_batch(self._m, th.shape[0], th.shape[1], _dp(th), _dp(out)))
         return out
+
+    def stretch_run(self, pos, nsteps: int, lnprob=None, a: float = 2.0, seed: int = 0, step0: int = 0,
+                    store_chain: bool = True, naccepted=None):
+        """``Engine.stretch_run`` for ONE ensemble sharded over this object's device contexts (``vp_multi_stretch_run``):
+        every context keeps the whole ensemble in HBM and runs its block of each half-step; moved rows are written into
+        every replica, half-steps are ordered by events.  Same arguments and results -- the same chain, bit for bit,
+        whatever the number of contexts."""
+        self._guard()
+        pos = np.array(pos, dtype=np.float64, order="C")
+        if pos.ndim != 2:
+            raise ValueError("pos must have shape (nwalkers, ndim)")
+        W, D = pos.shape
+        have = lnprob is not None
+        lp = np.array(lnprob, dtype=np.float64) if have else np.empty(W, dtype=np.float64)
+        if lp.shape != (W,):
+            raise ValueError("lnprob must have shape (nwalkers,)")
+        chain = np.empty((nsteps, W, D), dtype=np.float64) if store_chain else None
+        clp = np.empty((nsteps, W), dtype=np.float64) if store_chain else None
+        nacc = np.zeros(W, dtype=np.int64) if naccepted is None else np.ascontiguousarray(naccepted, dtype=np.int64)
+        rc = self._lib.vp_multi_stretch_run(self._m, W, D, _dp(pos), _dp(lp), 1 if have else 0, int(nsteps), float(a),
+                                            C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint64(int(step0)),
+                                            _dp(chain) if store_chain else None, _dp(clp) if store_chain else None,
+                                            nacc.ctypes.data_as(C.POINTER(C.c_int64)))
+        if rc == L.VP_ENAN:
+            raise ValueError("Probability function returned NaN")
+        self._check(rc)
+        return pos, lp, chain, clp, nacc

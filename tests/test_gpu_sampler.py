@@ -418,3 +418,45 @@ def test_device_slice_sampler_distribution_and_vfit_switch():
     lp = eng.lnprob(p0); lp[2] = -np.inf
     with pytest.raises(ValueError):
         eng.slice_run(p0, 2, lnprob=lp, seed=1)
+
+
+def _multi_for(wl, ids):
+    """A MultiEngine holding the workload's instrument(s) on the listed devices."""
+    import rbvfit_amd
+    m = rbvfit_amd.MultiEngine(ids)
+    m.set_bounds(wl.lb, wl.ub)
+    for data, (wave, flux, err) in zip(wl.tables, wl.spectra):
+        w = 1.0 / err ** 2
+        m.add_instrument(wave, flux, w, np.log(w), **data.engine_kwargs())
+    return m
+
+
+@pytest.mark.parametrize("walker", [1, 0])
+def test_sharded_ensemble_reproduces_the_single_context_chain(walker):
+    """vp_multi_stretch_run (BASELINE config 4's shape: ONE ensemble over several device contexts): device 0 listed two
+    and three times -- blocks of 13 + 12 and 9 + 9 + 7 rows per half-step, W/2 not divisible by G -- gives the chain of
+    vp_stretch_run on one context bit for bit, positions, lnprob, acceptance counts and all, through the one-launch
+    walker kernel (walker = 1) and through propose / lnprob / accept launches (walker = 0); runs can be split into calls."""
+    wl = _workload(W=50, pixels=700)
+    eng, p0 = wl.engine, wl.thetas
+    eng.set_option("walker", walker)
+    ref = eng.stretch_run(p0, 24, seed=5)
+    assert 0.1 < ref[4].sum() / (24 * 50) < 0.9          # the chain moves
+    for ids in ([0, 0], [0, 0, 0]):
+        with _multi_for(wl, ids) as m:
+            m.set_option("walker", walker)
+            got = m.stretch_run(p0, 24, seed=5)
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
+            # split into two calls, the second one with the state and lnprob of the first
+            first = m.stretch_run(p0, 10, seed=5, store_chain=False)
+            second = m.stretch_run(first[0], 14, lnprob=first[1], seed=5, step0=10, naccepted=first[4])
+            np.testing.assert_array_equal(second[0], ref[0])
+            np.testing.assert_array_equal(second[1], ref[1])
+            np.testing.assert_array_equal(second[2], ref[2][10:])
+            np.testing.assert_array_equal(second[4], ref[4])
+            bad = np.array(p0); bad[3, 1] = np.nan
+            with pytest.raises(ValueError, match="NaN"):
+                m.stretch_run(bad, 2, seed=1)
+            with pytest.raises(Exception, match="even"):
+                m.stretch_run(p0[:49], 2, seed=1)
