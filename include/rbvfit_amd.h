@@ -212,6 +212,14 @@ int vp_multi_lnprob_batch(vp_multi* m, int W, int D, const double* theta, double
  * evaluated with the launch structure the whole half-ensemble would get on one context.  At most 8 contexts. */
 int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
                          uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted);
+
+/* vp_slice_run for ONE ensemble on the contexts of `m`: every context keeps the whole sampler state and runs the same
+ * (deterministic) control kernels on it; each round's lnprob batch of trial rows is cut into blocks of ceil(B / G) rows,
+ * one per context, whose results are written into every replica (one double per row), with an event barrier per round.
+ * Arguments and results are those of vp_slice_run for any G, bit for bit.  At most 8 contexts. */
+int vp_multi_slice_run(vp_multi* m, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double* mu,
+                       int* tune, double tolerance, int patience, int maxsteps, uint64_t seed, uint64_t step0,
+                       double* chain, double* chain_lnprob, double* mu_history, int64_t* n_evals);
 const char* vp_multi_last_error(const vp_multi* m);
 
 /* The context's own stream (a hipStream_t, created non-blocking): what hip_stream == NULL selects in the

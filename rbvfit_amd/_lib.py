@@ -63,6 +63,8 @@ SIGNATURES = {
     "vp_multi_lnprob_batch": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp]),
     "vp_multi_stretch_run": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
                                        _dp, _dp, C.POINTER(C.c_int64)]),
+    "vp_multi_slice_run": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                     C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _dp, _dp, _dp, C.POINTER(C.c_int64)]),
     "vp_multi_last_error": (C.c_char_p, [_ctx]),
     "vp_philox4x32": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vp_profile_enable": (C.c_int, [_ctx, C.c_int]),

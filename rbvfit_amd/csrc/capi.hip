@@ -1109,6 +1109,202 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     return VP_OK;
 }
 
+// vp_slice_run on G >= 1 contexts (called with every context's mutex held).  G = 1 is the single-GPU sampler.  With G > 1
+// (vp_multi_slice_run) every context holds the whole sampler state and runs the SAME control kernels on it -- begin,
+// init, update, tune are deterministic functions of that state -- while each round's lnprob batch of B trial rows is cut
+// into blocks of ceil(B / G) rows, one per context, evaluated with the launch structure the whole batch would get
+// (policy_W), and written into EVERY replica's result vector (one double per row through peer-mapped pointers), followed
+// by the event barrier.  The replicas therefore stay identical bit for bit, and equal to the single-context run.
+static int multi_barrier(vp_multi* m);
+namespace { __global__ void scatter_rows_kernel(const double* __restrict__ src, int n, int lo, vp::Replicas R) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double v = src[k];
+    for (int r = 0; r < R.n; ++r) R.lp[r][lo + k] = v;        // (R.lp: the replicas' row-result vectors)
+} }
+
+static int slice_run_impl(vp_multi* m, vp_ctx* const* cx, int G, int W, int D, double* pos, double* lnprob, int have_lnprob,
+                          int nsteps, double* mu, int* tune, double tolerance, int patience, int maxsteps, uint64_t seed,
+                          uint64_t step0, double* chain, double* chain_lnprob, double* mu_history, int64_t* n_evals, int* bad) {
+    *bad = 0;
+    vp_ctx* c = cx[0];
+    int rc;
+#define SFAIL(i, code, msg) do { *bad = (i); return fail(cx[i], (code), (msg)); } while (0)
+#define STRY(i, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) SFAIL(i, VP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+    if (W < 4 || (W & 1) || W > 2 * vp::SLICE_MAX_HALF)
+        SFAIL(0, VP_EINVAL, "vp_slice_run: the number of walkers must be even, >= 4 and <= " + std::to_string(2 * vp::SLICE_MAX_HALF));
+    if (nsteps < 0 || !mu || !(*mu > 0.0) || !tune || maxsteps < 1 || patience < 1 || !(tolerance >= 0.0))
+        SFAIL(0, VP_EINVAL, "vp_slice_run: nsteps >= 0, mu > 0, maxsteps >= 1, patience >= 1, tolerance >= 0 and non-NULL mu/tune required");
+    if ((chain == nullptr) != (chain_lnprob == nullptr)) SFAIL(0, VP_EINVAL, "vp_slice_run: chain and chain_lnprob go together");
+    const int half = W / 2;
+    const int B = std::max(2, std::min(vp::SLICE_MAXC, c->tune.slice_rows)) * half;   // rows of every round's lnprob batch
+    const int per = (B + G - 1) / G;
+    // device state (doubles first): pos (W,D) | lp (W) | trial (B,D) | lnp_rows (B) | X0, eta (half,D each) |
+    // Z0, L, R (half each) | T (half, MAXC) | mu[3] | mu_hist (nsteps) | block results (per) | chain chunk; then the integer state
+    const size_t row = (size_t)W * (D + 1);
+    size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
+    const size_t nd = (size_t)W * D + W + (size_t)B * D + 2 * (size_t)B + 2 * (size_t)half * D + (3 + vp::SLICE_MAXC) * (size_t)half + 4 +
+                      (size_t)std::max(nsteps, 1) + (size_t)per;                // (lnp_rows twice: rounds alternate between the two when G > 1)
+    const size_t ni = (size_t)W + 7 * (size_t)half + 16;                       // perm | J K phase sides nshr row widx | n_active, nan, ncand
+    struct Dev { double *pos, *lp, *trial, *rows, *mu, *muhist, *blk, *chain; long long* ll; int *perm, *nact, *nan; vp::SliceState st; vp::SliceCounters cn; hipStream_t s; };
+    std::vector<Dev> dv(G);
+    const double h_mu[4] = {*mu, *tune > 0 ? (double)(*tune - 1) : 0.0, *tune ? 1.0 : 0.0, 0.0};   // `tune` carries the state across calls
+    for (int i = 0; i < G; ++i) {
+        vp_ctx* ci = cx[i];
+        STRY(i, hipSetDevice(ci->device));
+        if ((rc = ensure_workspace(ci, std::max(W, B)))) { *bad = i; return rc; }
+        const size_t bytes = (nd + (i == 0 ? chunk * row : 0)) * sizeof(double) + 4 * sizeof(long long) + ni * sizeof(int) + 64;
+        if ((rc = ensure_scratch(ci, bytes))) { *bad = i; return rc; }
+        Dev& d = dv[i];
+        d.s = ci->stream;
+        d.pos = ci->d_scratch; d.lp = d.pos + (size_t)W * D; d.trial = d.lp + W; d.rows = d.trial + (size_t)B * D;
+        d.st = vp::SliceState{};
+        d.st.X0 = d.rows + 2 * (size_t)B; d.st.eta = d.st.X0 + (size_t)half * D; d.st.Z0 = d.st.eta + (size_t)half * D;
+        d.st.L = d.st.Z0 + half; d.st.R = d.st.L + half; d.st.T = d.st.R + half;
+        d.mu = d.st.T + (size_t)half * vp::SLICE_MAXC;                        // 4 doubles (3 used)
+        d.muhist = d.mu + 4;
+        d.blk = d.muhist + std::max(nsteps, 1);
+        d.chain = d.blk + per;
+        d.ll = reinterpret_cast<long long*>(d.chain + (i == 0 ? chunk * row : 0));     // n_evals, nexp, ncon, (pad)
+        int* d_int = reinterpret_cast<int*>(d.ll + 4);
+        d.perm = d_int;
+        d.st.J = d.perm + W; d.st.K = d.st.J + half; d.st.phase = d.st.K + half; d.st.sides = d.st.phase + half; d.st.nshr = d.st.sides + half;
+        d.st.row = d.st.nshr + half; d.st.widx = d.st.row + half;
+        d.nact = d.st.widx + half;
+        d.nan = d.nact + 1;
+        d.cn = vp::SliceCounters{d.nact, d.ll, d.ll + 1, d.ll + 2, d.nan, d.nact + 2, d.mu};
+        STRY(i, hipMemcpyAsync(d.pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, d.s));
+        STRY(i, hipMemcpyAsync(d.mu, h_mu, sizeof(h_mu), hipMemcpyHostToDevice, d.s));
+        STRY(i, hipMemsetAsync(d.ll, 0, 4 * sizeof(long long), d.s));
+        STRY(i, hipMemsetAsync(d.nact, 0, 4 * sizeof(int), d.s));
+        ci->policy_W = 0;
+        if (have_lnprob) STRY(i, hipMemcpyAsync(d.lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, d.s));
+        else if ((rc = enqueue_lnprob(ci, W, d.pos, d.lp, d.s))) { *bad = i; return rc; }     // (every replica: once per run)
+    }
+    {   // the start state must be finite everywhere (zeus: "Invalid walker initial positions")
+        std::vector<double> h_lp(W);
+        STRY(0, hipSetDevice(c->device));
+        STRY(0, hipMemcpyAsync(h_lp.data(), dv[0].lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, dv[0].s));
+        STRY(0, hipStreamSynchronize(dv[0].s));
+        for (int w = 0; w < W; ++w)
+            if (!(std::fabs(h_lp[w]) <= 1.79e308))
+                SFAIL(0, VP_ENAN, "vp_slice_run: the initial lnprob of walker " + std::to_string(w) + " is not finite");
+    }
+    int parity = 0;                                  // which of the two row-result vectors the coming round fills (G > 1)
+    auto done_ = [&](int code) { for (int i = 0; i < G; ++i) cx[i]->policy_W = 0; return code; };
+    if (G > 1 && (rc = multi_barrier(m))) return done_(rc);
+    const double gamma0 = 2.38 / std::sqrt(2.0 * (double)D);
+    const int thr = ((half + 63) / 64) * 64;
+    int group = 6;                                   // rounds enqueued before the host looks at n_active (adapts to the run)
+    // one round: the lnprob of the B trial rows (sharded when G > 1), then the update kernel on every replica
+    auto round = [&](int h, uint64_t step) -> int {
+        const size_t roff = G > 1 ? (size_t)parity * B : 0;
+        vp::Replicas R{};
+        R.n = G;
+        for (int i = 0; i < G; ++i) { R.pos[i] = nullptr; R.lp[i] = dv[i].rows + roff; }
+        for (int i = 0; i < G; ++i) {
+            vp_ctx* ci = cx[i];
+            const Dev& d = dv[i];
+            STRY(i, hipSetDevice(ci->device));
+            if (G == 1) {
+                if ((rc = enqueue_lnprob(ci, B, d.trial, d.rows, d.s))) { *bad = i; return rc; }
+            } else {
+                const int lo = std::min(i * per, B), n = std::min(lo + per, B) - lo;
+                if (n <= 0) continue;
+                ci->policy_W = B;
+                if ((rc = enqueue_lnprob(ci, n, d.trial + (size_t)lo * D, d.blk, d.s))) { *bad = i; return rc; }
+                hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, d.s, d.blk, n, lo, R);
+            }
+        }
+        // every block's results are in every replica before any replica consumes them.  (The other hazard -- a block of
+        // the NEXT round landing in a vector a replica's update is still reading -- cannot occur: the rounds alternate
+        // between two vectors, and a replica's update of round r precedes, on its own stream, the event it records in
+        // round r + 1, which every scatter of round r + 2 waits for.)
+        if (G > 1 && (rc = multi_barrier(m))) return rc;
+        for (int i = 0; i < G; ++i) {
+            const Dev& d = dv[i];
+            STRY(i, hipSetDevice(cx[i]->device));
+            hipLaunchKernelGGL(vp::slice_update_kernel, dim3(1), dim3(thr), 0, d.s, d.pos, d.lp, d.rows + roff, half, D, h, seed,
+                               step, B, d.st, d.cn, d.trial);
+        }
+        parity ^= 1;
+        return VP_OK;
+    };
+    for (int done = 0; done < nsteps;) {
+        const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
+        for (int it = 0; it < n; ++it) {
+            const uint64_t step = step0 + (uint64_t)(done + it);
+            // mu tuning from the PREVIOUS iteration of this call, then this iteration's random split
+            for (int i = 0; i < G; ++i) {
+                const Dev& d = dv[i];
+                STRY(i, hipSetDevice(cx[i]->device));
+                hipLaunchKernelGGL(vp::slice_begin_kernel, dim3(1), dim3(1024), 0, d.s, W, seed, step, d.perm, d.cn, (done + it) > 0 ? 1 : 0,
+                                   tolerance, patience, (done + it) > 0 ? d.muhist + (done + it - 1) : (double*)nullptr);
+            }
+            for (int h = 0; h < 2; ++h) {
+                for (int i = 0; i < G; ++i) {
+                    const Dev& d = dv[i];
+                    STRY(i, hipSetDevice(cx[i]->device));
+                    hipLaunchKernelGGL(vp::slice_init_kernel, dim3(1), dim3(thr), 0, d.s, d.pos, d.lp, d.perm, half, D, h, seed, step,
+                                       gamma0, maxsteps, B, d.st, d.cn, d.trial);
+                }
+                int rounds = 0;
+                for (;;) {
+                    for (int r = 0; r < group; ++r)
+                        if ((rc = round(h, step))) return done_(rc);
+                    rounds += group;
+                    int h_state[2] = {0, 0};
+                    STRY(0, hipSetDevice(c->device));
+                    STRY(0, hipMemcpyAsync(h_state, dv[0].nact, 2 * sizeof(int), hipMemcpyDeviceToHost, dv[0].s));
+                    STRY(0, hipStreamSynchronize(dv[0].s));
+                    if (h_state[1]) { *bad = 0; return done_(fail(c, VP_ENAN, "vp_slice_run: Log Probability returned NaN")); }
+                    if (h_state[0] == 0) break;
+                    if (rounds > 4 * maxsteps + 4096) { *bad = 0; return done_(fail(c, VP_ESTATE, "vp_slice_run: a slice did not terminate")); }
+                    group = 2;                       // stragglers: look again after a couple of rounds
+                }
+                group = std::max(2, std::min(16, rounds));   // next half-step: about as many rounds as this one needed
+            }
+            if (chain) {
+                STRY(0, hipSetDevice(c->device));
+                STRY(0, hipMemcpyAsync(dv[0].chain + (size_t)it * W * D, dv[0].pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToDevice, dv[0].s));
+                STRY(0, hipMemcpyAsync(dv[0].chain + chunk * (size_t)W * D + (size_t)it * W, dv[0].lp, (size_t)W * sizeof(double),
+                                       hipMemcpyDeviceToDevice, dv[0].s));
+            }
+        }
+        STRY(0, hipGetLastError());
+        if (chain) {
+            STRY(0, hipSetDevice(c->device));
+            STRY(0, hipMemcpyAsync(chain + (size_t)done * W * D, dv[0].chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, dv[0].s));
+            STRY(0, hipMemcpyAsync(chain_lnprob + (size_t)done * W, dv[0].chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
+                                   hipMemcpyDeviceToHost, dv[0].s));
+            STRY(0, hipStreamSynchronize(dv[0].s));
+        }
+        done += n;
+    }
+    // the last iteration's tuning step (so that mu / mu_history cover every iteration of the call)
+    STRY(0, hipSetDevice(c->device));
+    if (nsteps > 0)
+        hipLaunchKernelGGL(vp::slice_tune_kernel, dim3(1), dim3(1), 0, dv[0].s, dv[0].cn, tolerance, patience, dv[0].muhist + (nsteps - 1));
+    double h_mu_out[4];
+    long long h_ll[4];
+    STRY(0, hipMemcpyAsync(pos, dv[0].pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, dv[0].s));
+    STRY(0, hipMemcpyAsync(lnprob, dv[0].lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, dv[0].s));
+    STRY(0, hipMemcpyAsync(h_mu_out, dv[0].mu, sizeof(h_mu_out), hipMemcpyDeviceToHost, dv[0].s));
+    STRY(0, hipMemcpyAsync(h_ll, dv[0].ll, sizeof(h_ll), hipMemcpyDeviceToHost, dv[0].s));
+    if (mu_history && nsteps > 0) STRY(0, hipMemcpyAsync(mu_history, dv[0].muhist, (size_t)nsteps * sizeof(double), hipMemcpyDeviceToHost, dv[0].s));
+    STRY(0, hipStreamSynchronize(dv[0].s));
+    for (int i = 1; i < G; ++i) {                                    // the other replicas have nothing left in flight either
+        STRY(i, hipSetDevice(cx[i]->device));
+        STRY(i, hipStreamSynchronize(dv[i].s));
+    }
+    *mu = h_mu_out[0];
+    *tune = h_mu_out[2] != 0.0 ? 1 + (int)h_mu_out[1] : 0;
+    if (n_evals) *n_evals += (int64_t)h_ll[0];
+#undef STRY
+#undef SFAIL
+    return done_(VP_OK);
+}
+
 int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double* mu,
                  int* tune, double tolerance, int patience, int maxsteps, uint64_t seed, uint64_t step0,
                  double* chain, double* chain_lnprob, double* mu_history, int64_t* n_evals) {
@@ -1116,122 +1312,10 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
     std::lock_guard<std::mutex> g(c->mu);
     int rc = check_batch_args(c, W, D, pos, lnprob);
     if (rc) return rc;
-    if (W < 4 || (W & 1) || W > 2 * vp::SLICE_MAX_HALF)
-        return fail(c, VP_EINVAL, "vp_slice_run: the number of walkers must be even, >= 4 and <= " + std::to_string(2 * vp::SLICE_MAX_HALF));
-    if (nsteps < 0 || !mu || !(*mu > 0.0) || !tune || maxsteps < 1 || patience < 1 || !(tolerance >= 0.0))
-        return fail(c, VP_EINVAL, "vp_slice_run: nsteps >= 0, mu > 0, maxsteps >= 1, patience >= 1, tolerance >= 0 and non-NULL mu/tune required");
-    if ((chain == nullptr) != (chain_lnprob == nullptr)) return fail(c, VP_EINVAL, "vp_slice_run: chain and chain_lnprob go together");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const int half = W / 2;
-    const int B = std::max(2, std::min(vp::SLICE_MAXC, c->tune.slice_rows)) * half;   // rows of every round's lnprob batch
-    if ((rc = ensure_workspace(c, std::max(W, B)))) return rc;
-    hipStream_t s = c->stream;
-    // device state (doubles first): pos (W,D) | lp (W) | trial (B,D) | lnp_rows (B) | X0, eta (half,D each) |
-    // Z0, L, R (half each) | T (half, MAXC) | mu[3] | mu_hist (nsteps) | chain chunk; then the integer state
-    const size_t row = (size_t)W * (D + 1);
-    size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
-    const size_t nd = (size_t)W * D + W + (size_t)B * D + B + 2 * (size_t)half * D + (3 + vp::SLICE_MAXC) * (size_t)half + 4 +
-                      (size_t)std::max(nsteps, 1);
-    const size_t ni = (size_t)W + 7 * (size_t)half + 16;                       // perm | J K phase sides nshr row widx | n_active, nan, ncand
-    const size_t bytes = (nd + chunk * row) * sizeof(double) + 4 * sizeof(long long) + ni * sizeof(int) + 64;
-    if ((rc = ensure_scratch(c, bytes))) return rc;
-    double* d_pos = c->d_scratch;
-    double* d_lp = d_pos + (size_t)W * D;
-    double* d_trial = d_lp + W;
-    double* d_rows = d_trial + (size_t)B * D;
-    vp::SliceState st{};
-    st.X0 = d_rows + B;
-    st.eta = st.X0 + (size_t)half * D;
-    st.Z0 = st.eta + (size_t)half * D;
-    st.L = st.Z0 + half; st.R = st.L + half; st.T = st.R + half;
-    double* d_mu = st.T + (size_t)half * vp::SLICE_MAXC;                       // 4 doubles (3 used)
-    double* d_muhist = d_mu + 4;
-    double* d_chain = d_muhist + std::max(nsteps, 1);
-    long long* d_ll = reinterpret_cast<long long*>(d_chain + chunk * row);     // n_evals, nexp, ncon, (pad)
-    int* d_int = reinterpret_cast<int*>(d_ll + 4);
-    int* d_perm = d_int;
-    st.J = d_perm + W; st.K = st.J + half; st.phase = st.K + half; st.sides = st.phase + half; st.nshr = st.sides + half;
-    st.row = st.nshr + half; st.widx = st.row + half;
-    int* d_nact = st.widx + half;
-    int* d_nan = d_nact + 1;
-    vp::SliceCounters cn{d_nact, d_ll, d_ll + 1, d_ll + 2, d_nan, d_nact + 2, d_mu};
-    // `tune` carries the tuning state across calls: 0 off, n >= 1 on with n - 1 consecutive in-tolerance iterations so far
-    const double h_mu[4] = {*mu, *tune > 0 ? (double)(*tune - 1) : 0.0, *tune ? 1.0 : 0.0, 0.0};
-    HIP_TRY(c, hipMemcpyAsync(d_pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d_mu, h_mu, sizeof(h_mu), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemsetAsync(d_ll, 0, 4 * sizeof(long long), s));
-    HIP_TRY(c, hipMemsetAsync(d_nact, 0, 4 * sizeof(int), s));
-    if (have_lnprob) HIP_TRY(c, hipMemcpyAsync(d_lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, s));
-    else if ((rc = enqueue_lnprob(c, W, d_pos, d_lp, s))) return rc;
-    {   // the start state must be finite everywhere (zeus: "Invalid walker initial positions")
-        std::vector<double> h_lp(W);
-        HIP_TRY(c, hipMemcpyAsync(h_lp.data(), d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        for (int w = 0; w < W; ++w)
-            if (!(std::fabs(h_lp[w]) <= 1.79e308))
-                return fail(c, VP_ENAN, "vp_slice_run: the initial lnprob of walker " + std::to_string(w) + " is not finite");
-    }
-    const double gamma0 = 2.38 / std::sqrt(2.0 * (double)D);
-    const int thr = ((half + 63) / 64) * 64;
-    int group = 6;                                   // rounds enqueued before the host looks at n_active (adapts to the run)
-    for (int done = 0; done < nsteps;) {
-        const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
-        for (int it = 0; it < n; ++it) {
-            const uint64_t step = step0 + (uint64_t)(done + it);
-            // mu tuning from the PREVIOUS iteration of this call, then this iteration's random split
-            hipLaunchKernelGGL(vp::slice_begin_kernel, dim3(1), dim3(1024), 0, s, W, seed, step, d_perm, cn, (done + it) > 0 ? 1 : 0,
-                               tolerance, patience, (done + it) > 0 ? d_muhist + (done + it - 1) : (double*)nullptr);
-            for (int h = 0; h < 2; ++h) {
-                hipLaunchKernelGGL(vp::slice_init_kernel, dim3(1), dim3(thr), 0, s, d_pos, d_lp, d_perm, half, D, h, seed, step,
-                                   gamma0, maxsteps, B, st, cn, d_trial);
-                int rounds = 0;
-                for (;;) {
-                    for (int r = 0; r < group; ++r) {
-                        if ((rc = enqueue_lnprob(c, B, d_trial, d_rows, s))) return rc;
-                        hipLaunchKernelGGL(vp::slice_update_kernel, dim3(1), dim3(thr), 0, s, d_pos, d_lp, d_rows, half, D, h, seed,
-                                           step, B, st, cn, d_trial);
-                    }
-                    rounds += group;
-                    int h_state[2] = {0, 0};
-                    HIP_TRY(c, hipMemcpyAsync(h_state, d_nact, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(c, hipStreamSynchronize(s));
-                    if (h_state[1]) return fail(c, VP_ENAN, "vp_slice_run: Log Probability returned NaN");
-                    if (h_state[0] == 0) break;
-                    if (rounds > 4 * maxsteps + 4096) return fail(c, VP_ESTATE, "vp_slice_run: a slice did not terminate");
-                    group = 2;                       // stragglers: look again after a couple of rounds
-                }
-                group = std::max(2, std::min(16, rounds));   // next half-step: about as many rounds as this one needed
-            }
-            if (chain) {
-                HIP_TRY(c, hipMemcpyAsync(d_chain + (size_t)it * W * D, d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToDevice, s));
-                HIP_TRY(c, hipMemcpyAsync(d_chain + chunk * (size_t)W * D + (size_t)it * W, d_lp, (size_t)W * sizeof(double),
-                                          hipMemcpyDeviceToDevice, s));
-            }
-        }
-        HIP_TRY(c, hipGetLastError());
-        if (chain) {
-            HIP_TRY(c, hipMemcpyAsync(chain + (size_t)done * W * D, d_chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipMemcpyAsync(chain_lnprob + (size_t)done * W, d_chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
-                                      hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
-        }
-        done += n;
-    }
-    // the last iteration's tuning step (so that mu / mu_history cover every iteration of the call)
-    if (nsteps > 0)
-        hipLaunchKernelGGL(vp::slice_tune_kernel, dim3(1), dim3(1), 0, s, cn, tolerance, patience, d_muhist + (nsteps - 1));
-    double h_mu_out[4];
-    long long h_ll[4];
-    HIP_TRY(c, hipMemcpyAsync(pos, d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(lnprob, d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(h_mu_out, d_mu, sizeof(h_mu_out), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(h_ll, d_ll, sizeof(h_ll), hipMemcpyDeviceToHost, s));
-    if (mu_history && nsteps > 0) HIP_TRY(c, hipMemcpyAsync(mu_history, d_muhist, (size_t)nsteps * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    *mu = h_mu_out[0];
-    *tune = h_mu_out[2] != 0.0 ? 1 + (int)h_mu_out[1] : 0;
-    if (n_evals) *n_evals += (int64_t)h_ll[0];
-    return VP_OK;
+    int bad = 0;
+    vp_ctx* cx[1] = {c};
+    return slice_run_impl(nullptr, cx, 1, W, D, pos, lnprob, have_lnprob, nsteps, mu, tune, tolerance, patience, maxsteps, seed, step0,
+                          chain, chain_lnprob, mu_history, n_evals, &bad);
 }
 
 #ifdef VP_STAMPS
@@ -1637,6 +1721,32 @@ int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob,
 #undef MTRY
     if (any_nan) { c0->err = "vp_multi_stretch_run: Probability function returned NaN"; return finish(multi_fail(m, 0, VP_ENAN)); }
     return finish(VP_OK);
+}
+
+int vp_multi_slice_run(vp_multi* m, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double* mu,
+                       int* tune, double tolerance, int patience, int maxsteps, uint64_t seed, uint64_t step0,
+                       double* chain, double* chain_lnprob, double* mu_history, int64_t* n_evals) {
+    if (!m) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(m->mu);
+    if (m->broken) return multi_broken(m);
+    const int G = (int)m->ctx.size();
+    if (G > vp::MAX_REPLICAS) { m->err = "vp_multi_slice_run: at most " + std::to_string(vp::MAX_REPLICAS) + " device contexts"; return VP_EINVAL; }
+    if (m->no_peer) { m->err = "vp_multi_slice_run: the devices cannot map each other's memory (no peer access)"; return VP_ESTATE; }
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (int i = 0; i < G; ++i) locks.emplace_back(m->ctx[i]->mu);
+    for (int i = 0; i < G; ++i)
+        if (int rc = check_batch_args(m->ctx[i], W, D, pos, lnprob)) return multi_fail(m, i, rc);
+    for (int i = (int)m->ev.size(); i < G; ++i) {
+        hipEvent_t e;
+        if (hipSetDevice(m->ctx[i]->device) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            m->ctx[i]->err = "hipEventCreate failed"; return multi_fail(m, i, VP_EHIP);
+        }
+        m->ev.push_back(e);
+    }
+    int bad = 0;
+    const int rc = slice_run_impl(m, m->ctx.data(), G, W, D, pos, lnprob, have_lnprob, nsteps, mu, tune, tolerance, patience, maxsteps,
+                                  seed, step0, chain, chain_lnprob, mu_history, n_evals, &bad);
+    return rc ? multi_fail(m, bad, rc) : VP_OK;
 }
 
 void* vp_ctx_stream(const vp_ctx* c) { return c ? (void*)c->stream : nullptr; }

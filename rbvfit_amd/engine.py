@@ -414,3 +414,33 @@ class MultiEngine:
             raise ValueError("Probability function returned NaN")
         self._check(rc)
         return pos, lp, chain, clp, nacc
+
+    def slice_run(self, pos, nsteps: int, lnprob=None, mu: float = 1.0, tune=True, tolerance: float = 0.05,
+                  patience: int = 5, maxsteps: int = 10000, seed: int = 0, step0: int = 0, store_chain: bool = True):
+        """``Engine.slice_run`` for ONE ensemble on this object's device contexts (``vp_multi_slice_run``): the sampler
+        state is replicated, every round's lnprob batch is cut into one block of trial rows per context.  Same arguments
+        and results -- the same chain, bit for bit, whatever the number of contexts."""
+        self._guard()
+        pos = np.array(pos, dtype=np.float64, order="C")
+        if pos.ndim != 2:
+            raise ValueError("pos must have shape (nwalkers, ndim)")
+        W, D = pos.shape
+        have = lnprob is not None
+        lp = np.array(lnprob, dtype=np.float64) if have else np.empty(W, dtype=np.float64)
+        if lp.shape != (W,):
+            raise ValueError("lnprob must have shape (nwalkers,)")
+        chain = np.empty((nsteps, W, D), dtype=np.float64) if store_chain else None
+        clp = np.empty((nsteps, W), dtype=np.float64) if store_chain else None
+        hist = np.empty(max(nsteps, 1), dtype=np.float64)
+        c_mu, c_tune, c_ne = C.c_double(float(mu)), C.c_int(int(tune) if tune else 0), C.c_int64(0)
+        rc = self._lib.vp_multi_slice_run(self._m, W, D, _dp(pos), _dp(lp), 1 if have else 0, int(nsteps), C.byref(c_mu),
+                                          C.byref(c_tune), float(tolerance), int(patience), int(maxsteps),
+                                          C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint64(int(step0)),
+                                          _dp(chain) if store_chain else None, _dp(clp) if store_chain else None, _dp(hist),
+                                          C.byref(c_ne))
+        if rc == L.VP_ENAN:
+            msg = self._lib.vp_multi_last_error(self._m)
+            raise ValueError(msg.decode() if msg else "Log Probability returned NaN")
+        self._check(rc)
+        return dict(pos=pos, lnprob=lp, chain=chain, chain_lnprob=clp, mu=c_mu.value, tune=bool(c_tune.value),
+                    tune_state=int(c_tune.value), mu_history=hist[:nsteps], n_evals=int(c_ne.value))

@@ -460,3 +460,24 @@ def test_sharded_ensemble_reproduces_the_single_context_chain(walker):
                 m.stretch_run(bad, 2, seed=1)
             with pytest.raises(Exception, match="even"):
                 m.stretch_run(p0[:49], 2, seed=1)
+
+
+@pytest.mark.parametrize("walker", [1, 0])
+def test_sharded_slice_sampler_reproduces_the_single_context_chain(walker):
+    """vp_multi_slice_run: replicated sampler state, every round's lnprob batch cut into one block of trial rows per
+    context (device 0 listed two and three times: 25 + 25 and 17 + 17 + 16 rows) -- chain, lnprob, mu history and the
+    count of evaluations of vp_slice_run on one context, bit for bit."""
+    wl = _workload(W=50, pixels=700)
+    eng, p0 = wl.engine, wl.thetas
+    eng.set_option("walker", walker)
+    ref = eng.slice_run(p0, 12, seed=9)
+    for ids in ([0, 0], [0, 0, 0]):
+        with _multi_for(wl, ids) as m:
+            m.set_option("walker", walker)
+            got = m.slice_run(p0, 12, seed=9)
+            for k in ("pos", "lnprob", "chain", "chain_lnprob", "mu_history"):
+                np.testing.assert_array_equal(ref[k], got[k], err_msg=k)
+            assert (ref["mu"], ref["tune_state"], ref["n_evals"]) == (got["mu"], got["tune_state"], got["n_evals"])
+            lp = eng.lnprob(p0); lp[2] = -np.inf
+            with pytest.raises(ValueError, match="not finite"):
+                m.slice_run(p0, 2, lnprob=lp, seed=1)
