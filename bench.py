@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the config's TOTAL walker count (or --walkers x 1) split over the GPUs")
     ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps passes (0 = enough for 0.25 s)")
+    ap.add_argument("--spread", default="ball", choices=["ball", "posterior"],
+                    help="walker positions of the timed passes: 'ball' = SURVEY 8(d)'s 1e-3 ball around theta_true (the default, what "
+                         "`value` is defined on), 'posterior' = the ensemble after a burn-in of the device-resident stretch sampler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs that are not part of `value` (copy bandwidth, host-entry latency, device sampler): "
@@ -265,6 +268,17 @@ def rank_main(args):
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
+
+    def burned_in(nsteps=None):
+        """The rank's walkers after a burn-in of the device-resident stretch sampler: a posterior-width ensemble."""
+        if nsteps is None:
+            nsteps = 1500 if args.config in ("C0", "C1") else (200 if args.config in ("C2", "C3") else 60)
+        return np.ascontiguousarray(wl.engine.stretch_run(wl.thetas, nsteps, seed=7 + rank, store_chain=False)[0])
+
+    spread_note = "1e-3 ball around theta_true (SURVEY 8d)"
+    if args.spread == "posterior":
+        wl.thetas = burned_in()
+        spread_note = "ensemble after a stretch-move burn-in (posterior width)"
     d_theta = torch.from_numpy(wl.thetas).cuda()
     d_out = torch.empty(W, dtype=torch.float64, device="cuda")
     gathered = torch.empty(W * world, dtype=torch.float64, device="cuda") if use_dist else None
@@ -373,12 +387,31 @@ def rank_main(args):
                     break
         except Exception:
             pass
+        valu_issue = None
+        try:
+            if traffic_src is not None and "sq" in pm and pm["sq"].get("SQ_INSTS_VALU"):
+                # measured issue utilisation of the dominant kernel in the committed counter run: wave-level VALU instructions
+                # x 4 cycles (what one costs a SIMD at full rate) / (1024 SIMDs x the kernel's duration in that run x 2.4 GHz)
+                kus = float(pm["rocprofv3_mean_kernel_us"])
+                nv = float(pm["sq"]["SQ_INSTS_VALU"])
+                valu_issue = dict(frac=nv * 4.0 / (1024.0 * kus * 1e-6 * 2.4e9), valu_insts_per_launch=nv,
+                                  valu_insts_per_eval=nv / W, kernel_us_in_counter_run=kus, cycles_per_inst=4.0, simds=1024,
+                                  clock_GHz=2.4, source=traffic_src,
+                                  note="the roof that binds this kernel: fp64 VALU issue.  frac = SQ_INSTS_VALU x 4 cycles / "
+                                       "(SIMDs x kernel time x clock) from the committed rocprofv3 --pmc run of this command; "
+                                       "`achieved` of this object restates the live kernel time as instructions issued per second")
+                valu_issue["achieved_Ginst_per_s"] = nv / (tile_ms * 1e-3) / 1e9
+                valu_issue["peak_Ginst_per_s"] = 1024 * 2.4 / 4.0
+                valu_issue["frac_live"] = valu_issue["achieved_Ginst_per_s"] / valu_issue["peak_Ginst_per_s"]
+        except Exception:
+            valu_issue = None
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, traffic_source=traffic_src, kernel=kernel_name, avg_kernel_ms=tile_ms, kernel_timing=timing_note,
                     algorithmic_bytes_per_launch=bytes_per_launch, launches_per_step=pr["n_tile_launches"] / nprof,
                     prep_ms=pr["prep_ms"] / nprof, finalize_ms=pr.get("finalize_ms", 0.0) / nprof,
                     note="kernel is fp64-VALU / latency bound; spectra are shared by all walkers through L2/MALL, "
                          "so measured HBM traffic is far below the algorithmic bytes (DESIGN.md section 4)")
+        roof["valu_issue"] = valu_issue
         # secondary roof: fp64 VALU, with the survey's flop model
         flops = wl.algorithmic_flops_per_eval * W
         vt = flops / len(wl.pixels) / (tile_ms * 1e-3) / 1e12
@@ -436,6 +469,55 @@ def rank_main(args):
                     slice_info = dict(steps_per_sec=nsl / dts, lnprob_evals_per_walker_step=r1["n_evals"] / (nsl * W),
                                       evals_per_sec=r1["n_evals"] / dts, mu=r1["mu"])
 
+        spread_info = multi_info = None
+        if not args.no_extras and W % 2 == 0 and args.spread == "ball":
+            # the same passes on a posterior-width ensemble (walkers' line cores no longer in the same tiles)
+            try:
+                th_post = burned_in()
+                d_post = torch.from_numpy(th_post).cuda()
+                torch.cuda.synchronize()
+                for _ in range(50):
+                    eng.lnprob_device(d_post.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                npass = nprof
+                e0.record(stream)
+                for _ in range(npass):
+                    eng.lnprob_device(d_post.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms_post = e0.elapsed_time(e1) / npass
+                sd = th_post.std(axis=0)
+                spread_info = dict(evals_per_sec=W / (ms_post * 1e-3), ms_per_step=ms_post, ms_per_step_ball=step_ev_ms,
+                                   theta_std_min=float(sd.min()), theta_std_max=float(sd.max()),
+                                   note="lnprob passes on the ensemble a stretch-move burn-in leaves (posterior width) next to the "
+                                        "1e-3 ball `value` is defined on; HIP events around back-to-back passes")
+                eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)     # d_out = the ball's result again
+                torch.cuda.synchronize()
+            except Exception as e:
+                spread_info = {"error": str(e)}
+            # one ensemble sharded over TWO device contexts on this one GPU (vp_multi_stretch_run, device listed twice): what the
+            # exchange of moved rows + the event barrier per half-step cost next to the single-context sampler
+            try:
+                import rbvfit_amd
+                nst = 300 if args.config in ("C0", "C1") else 20
+                with rbvfit_amd.MultiEngine([local_rank, local_rank]) as me:
+                    me.set_bounds(wl.lb, wl.ub)
+                    for data, (wave, flux, err) in zip(wl.tables, wl.spectra):
+                        wgt = 1.0 / err ** 2
+                        me.add_instrument(wave, flux, wgt, np.log(wgt), **data.engine_kwargs())
+                    me.stretch_run(wl.thetas, max(2, nst // 15), seed=1, store_chain=False)
+                    ts0 = time.perf_counter()
+                    me.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
+                    multi_steps = nst / (time.perf_counter() - ts0)
+                multi_info = dict(steps_per_sec_two_contexts_one_gpu=multi_steps, steps_per_sec_one_context=sampler_steps,
+                                  us_per_half_step_two_contexts=0.5e6 / multi_steps,
+                                  us_per_half_step_one_context=(0.5e6 / sampler_steps) if sampler_steps else None,
+                                  note="vp_multi_stretch_run with this GPU listed twice: two half-size kernels side by side, moved rows "
+                                       "written into both replicas, 2 event records + 2 stream waits per half-step, against "
+                                       "vp_stretch_run; both chains are identical bit for bit")
+            except Exception as e:
+                multi_info = {"error": str(e)}
+
     result = d_out.cpu().numpy()
     if rank == 0:
         evals = W * world * args.steps
@@ -458,8 +540,14 @@ def rank_main(args):
             "slice_sampler": slice_info,
             "slice_sampler_note": "device-resident ensemble slice sampling (vp_slice_run, zeus' differential move): ensemble steps/s, "
                                   "lnprob evaluations per walker and step, and the evaluations/s they amount to",
+            "seam_evals_per_sec": host_rate,
+            "seam_note": "what a caller of the reference's seam gets: vp_lnprob_batch with host buffers (emcee vectorize=True, the "
+                         "INTEGRATION.md stub), H2D theta + kernels + D2H lnprob + sync per call -- `value` is the device-resident rate",
             "host_entry_evals_per_sec_pcie_inclusive": host_rate,
             "host_entry_latency": host_lat,
+            "walker_spread": spread_note,
+            "posterior_spread": spread_info if not args.no_extras else None,
+            "sharded_sampler_one_gpu": multi_info if not args.no_extras else None,
             "roofline": roof,
         }
         if use_dist:

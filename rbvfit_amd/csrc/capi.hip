@@ -44,6 +44,11 @@ struct Tuning {
     int walker_clusters = 0;    // walker_kernel on instruments with multipole clusters: 0 = walk the member lines one by one
                                 // (no cluster records: the plain instance), 1 = cluster records formed in the workgroup
                                 // (that instance spills to scratch)
+    int multi_sync = 0;         // vp_multi_stretch_run: how the contexts' half-steps are ordered (read from context 0): 0 events between
+                                // their streams (default), 1 flags polled inside the kernels -- no host call and no cross-queue wait per
+                                // half-step; tested with the contexts on ONE device, where it measured no faster than events because the
+                                // contexts' kernels share the CUs (C1, 2 contexts: 49.9 vs 39.5 us per half-step; C3 at 2048 walkers:
+                                // 257 vs 272); across devices it uses system-scope fences and has never run
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
 
@@ -56,7 +61,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
-    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0),
+    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -1594,25 +1599,31 @@ int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob,
         }
     }
     const int half = W / 2, per = (half + G - 1) / G;
-    // device state per context: pos (W,D) | lp (W) | prop (per,D) | lp_new (per) | zz (per) | [chain chunk: replica 0] ; nacc (W) | nanflag
+    bool one_device = true;
+    for (int i = 1; i < G; ++i) one_device = one_device && m->ctx[i]->device == c0->device;
+    const bool flags_mode = c0->tune.multi_sync > 0;
+    // device state per context: pos (W,D) | lp (W) | prop (per,D) | lp_new (per) | zz (per) | chain chunk (flags mode: every
+    // context keeps the rows of ITS walkers; events mode: replica 0 snapshots the ensemble) ; nacc (W) | nanflag | flags (G) | done | timeout
     const size_t row = (size_t)W * (D + 1);
     const size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
-    struct Dev { double *pos, *lp, *prop, *lpnew, *zz, *chain; long long* nacc; int* nan; };
+    struct Dev { double *pos, *lp, *prop, *lpnew, *zz, *chain; long long* nacc; int *nan, *flags, *timeout; unsigned int* done; };
     std::vector<Dev> dv(G);
     for (int i = 0; i < G; ++i) {
         vp_ctx* c = m->ctx[i];
 #define MTRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e__); return multi_fail(m, i, VP_EHIP); } } while (0)
         MTRY(hipSetDevice(c->device));
         if ((rc = ensure_workspace(c, std::max(W, per)))) return multi_fail(m, i, rc);
-        const size_t nd = (size_t)W * D + W + (size_t)per * D + 2 * (size_t)per + (i == 0 ? chunk * row : 0);
-        if ((rc = ensure_scratch(c, nd * sizeof(double) + (size_t)W * sizeof(long long) + 64))) return multi_fail(m, i, rc);
+        const size_t nchain = (flags_mode || i == 0) ? chunk * row : 0;
+        const size_t nd = (size_t)W * D + W + (size_t)per * D + 2 * (size_t)per + nchain;
+        if ((rc = ensure_scratch(c, nd * sizeof(double) + (size_t)W * sizeof(long long) + (vp::MAX_REPLICAS + 4) * sizeof(int) + 64))) return multi_fail(m, i, rc);
         Dev& d = dv[i];
         d.pos = c->d_scratch; d.lp = d.pos + (size_t)W * D; d.prop = d.lp + W; d.lpnew = d.prop + (size_t)per * D;
         d.zz = d.lpnew + per; d.chain = d.zz + per;
-        d.nacc = reinterpret_cast<long long*>(d.chain + (i == 0 ? chunk * row : 0));
+        d.nacc = reinterpret_cast<long long*>(d.chain + nchain);
         d.nan = reinterpret_cast<int*>(d.nacc + W);
+        d.flags = d.nan + 1; d.done = reinterpret_cast<unsigned int*>(d.flags + vp::MAX_REPLICAS); d.timeout = reinterpret_cast<int*>(d.done + 1);
         MTRY(hipMemcpyAsync(d.pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        MTRY(hipMemsetAsync(d.nacc, 0, (size_t)W * sizeof(long long) + sizeof(int), c->stream));
+        MTRY(hipMemsetAsync(d.nacc, 0, (size_t)W * sizeof(long long) + (vp::MAX_REPLICAS + 4) * sizeof(int), c->stream));
         if (have_lnprob) MTRY(hipMemcpyAsync(d.lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, c->stream));
         else {
             // every replica evaluates the whole start state itself (once per run; the same launches as vp_stretch_run's)
@@ -1629,47 +1640,64 @@ int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob,
         MTRY(hipStreamSynchronize(c->stream));
         if (h_nan0) { c0->err = "vp_multi_stretch_run: the initial lnprob holds NaN (Probability function returned NaN)"; return multi_fail(m, 0, VP_ENAN); }
     }
-    vp::Replicas R{};
-    R.n = G;
-    for (int i = 0; i < G; ++i) { R.pos[i] = dv[i].pos; R.lp[i] = dv[i].lp; }
+    // every replica's start state (and its zeroed flags) is in place before any kernel of the run starts
+    for (int i = 0; i < G; ++i) {
+        vp_ctx* c = m->ctx[i];
+        MTRY(hipSetDevice(c->device));
+        MTRY(hipStreamSynchronize(c->stream));
+    }
     const int thr = 64;
     auto finish = [&](int code) { for (int i = 0; i < G; ++i) m->ctx[i]->policy_W = 0; return code; };
-    if ((rc = multi_barrier(m))) return finish(multi_fail(m, 0, rc));             // every replica's start state is in place
+    std::vector<double> h_chunk;                       // flags mode: one context's chain chunk on its way to the caller's arrays
+    int seq = 0;                                       // half-steps of this call so far
     for (int done = 0; done < nsteps;) {
         const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
         for (int it = 0; it < n; ++it) {
             const uint64_t step = step0 + (uint64_t)(done + it);
             for (int h = 0; h < 2; ++h) {
                 const int s0 = h ? half : 0, cc0 = h ? 0 : half;
+                ++seq;
                 for (int i = 0; i < G; ++i) {
                     vp_ctx* c = m->ctx[i];
                     const int k0 = std::min(i * per, half), nk = std::min(k0 + per, half) - k0;
-                    if (nk <= 0) continue;
                     MTRY(hipSetDevice(c->device));
                     c->policy_W = half;
                     const Dev& d = dv[i];
+                    vp::Replicas R{};
+                    R.n = G;
+                    for (int j = 0; j < G; ++j) { R.pos[j] = dv[j].pos; R.lp[j] = dv[j].lp; R.flags[j] = dv[j].flags; }
+                    R.done = d.done; R.timeout = d.timeout; R.me = i; R.seq = seq; R.sync = flags_mode ? (one_device ? 1 : 2) : 0;
+                    double* cp = (chain && flags_mode) ? d.chain + (size_t)it * W * D : (double*)nullptr;
+                    double* cl = (chain && flags_mode) ? d.chain + chunk * (size_t)W * D + (size_t)it * W : (double*)nullptr;
+                    if (nk <= 0) {
+                        // (a context without rows in this half still has to tell the others that it is through)
+                        if (flags_mode)
+                            hipLaunchKernelGGL(vp::stretch_accept_block_kernel, dim3(1), dim3(thr), 0, c->stream, d.pos, d.lp, R, d.prop, d.lpnew,
+                                               d.zz, D, s0, k0, 0, seed, step, h, d.nacc, d.nan, cp, cl);
+                        continue;
+                    }
                     // (the choice vp_stretch_run makes for the whole half)
                     const bool one_launch = !c->tune.no_fused_accept && c->tune.walker != 0 && walker_applies(c, half) &&
                                             (c->inst[0].dev.NCm == 0 || !c->tune.walker_clusters);
                     if (one_launch) {
                         vp::StretchArgs sa{};
                         sa.pos = d.pos; sa.lp = d.lp; sa.nacc = d.nacc; sa.nanflag = d.nan;
-                        sa.chain_pos = nullptr; sa.chain_lp = nullptr;
+                        sa.chain_pos = cp; sa.chain_lp = cl;
                         sa.a = a; sa.seed = seed; sa.step = step; sa.s0 = s0 + k0; sa.c0 = cc0; sa.nC = half; sa.half = h;
                         sa.rep = R;
                         launch_walker_stretch(c, nk, sa, c->stream);
                     } else {
                         hipLaunchKernelGGL(vp::stretch_propose_block_kernel, dim3((nk + thr - 1) / thr), dim3(thr), 0, c->stream, d.pos, D, s0,
-                                           half, cc0, half, a, seed, step, h, k0, nk, d.prop, d.zz);
+                                           half, cc0, half, a, seed, step, h, k0, nk, d.prop, d.zz, R);
                         if ((rc = enqueue_lnprob(c, nk, d.prop, d.lpnew, c->stream))) return finish(multi_fail(m, i, rc));
-                        hipLaunchKernelGGL(vp::stretch_accept_block_kernel, dim3((nk + thr - 1) / thr), dim3(thr), 0, c->stream, d.lp, R,
-                                           d.prop, d.lpnew, d.zz, D, s0, k0, nk, seed, step, h, d.nacc, d.nan);
+                        hipLaunchKernelGGL(vp::stretch_accept_block_kernel, dim3((nk + thr - 1) / thr), dim3(thr), 0, c->stream, d.pos, d.lp, R,
+                                           d.prop, d.lpnew, d.zz, D, s0, k0, nk, seed, step, h, d.nacc, d.nan, cp, cl);
                     }
                     MTRY(hipGetLastError());
                 }
-                if ((rc = multi_barrier(m))) return finish(multi_fail(m, 0, rc));
+                if (!flags_mode && (rc = multi_barrier(m))) return finish(multi_fail(m, 0, rc));
             }
-            if (chain) {
+            if (chain && !flags_mode) {
                 vp_ctx* c = c0; const int i = 0;
                 MTRY(hipSetDevice(c->device));
                 MTRY(hipMemcpyAsync(dv[0].chain + (size_t)it * W * D, dv[0].pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1685,33 +1713,58 @@ int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob,
                 }
             }
         }
-        if (chain) {
+        if (chain && !flags_mode) {
             vp_ctx* c = c0; const int i = 0;
             MTRY(hipSetDevice(c->device));
             MTRY(hipMemcpyAsync(chain + (size_t)done * W * D, dv[0].chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             MTRY(hipMemcpyAsync(chain_lnprob + (size_t)done * W, dv[0].chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
                                 hipMemcpyDeviceToHost, c->stream));
             MTRY(hipStreamSynchronize(c->stream));
-            // (the other replicas must not run ahead into the chunk buffer's next use: they only ever wait on events of
-            //  kernels, and replica 0's next kernels are enqueued behind these copies on its stream)
+        }
+        if (chain && flags_mode) {
+            // every context holds the chain rows of the walkers it moves (blocks k0 ... of both halves): merged here
+            h_chunk.resize((size_t)n * row);
+            for (int i = 0; i < G; ++i) {
+                vp_ctx* c = m->ctx[i];
+                const int k0 = std::min(i * per, half), nk = std::min(k0 + per, half) - k0;
+                if (nk <= 0) continue;
+                MTRY(hipSetDevice(c->device));
+                MTRY(hipMemcpyAsync(h_chunk.data(), dv[i].chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                MTRY(hipMemcpyAsync(h_chunk.data() + (size_t)n * W * D, dv[i].chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
+                                    hipMemcpyDeviceToHost, c->stream));
+                MTRY(hipStreamSynchronize(c->stream));
+                for (int t = 0; t < n; ++t)
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const size_t w0 = (size_t)hh * half + k0;
+                        std::memcpy(chain + ((size_t)(done + t) * W + w0) * D, h_chunk.data() + ((size_t)t * W + w0) * D, (size_t)nk * D * sizeof(double));
+                        std::memcpy(chain_lnprob + (size_t)(done + t) * W + w0, h_chunk.data() + (size_t)n * W * D + (size_t)t * W + w0,
+                                    (size_t)nk * sizeof(double));
+                    }
+            }
         }
         done += n;
     }
     // results: the ensemble from replica 0, every walker's acceptance count from the context that moved it, NaN flags from all
-    int any_nan = 0;
+    int any_nan = 0, any_timeout = 0;
     std::vector<long long> h_nacc(W);
+    for (int i = 0; i < G; ++i) {                      // (flags mode: replica 0 is complete only when every context is through)
+        vp_ctx* c = m->ctx[i];
+        MTRY(hipSetDevice(c->device));
+        MTRY(hipStreamSynchronize(c->stream));
+    }
     for (int i = 0; i < G; ++i) {
         vp_ctx* c = m->ctx[i];
         MTRY(hipSetDevice(c->device));
-        int h_nan = 0;
+        int h_nan = 0, h_to = 0;
         MTRY(hipMemcpyAsync(&h_nan, dv[i].nan, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        MTRY(hipMemcpyAsync(&h_to, dv[i].timeout, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         MTRY(hipMemcpyAsync(h_nacc.data(), dv[i].nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
         if (i == 0) {
             MTRY(hipMemcpyAsync(pos, dv[0].pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             MTRY(hipMemcpyAsync(lnprob, dv[0].lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         }
         MTRY(hipStreamSynchronize(c->stream));
-        any_nan |= h_nan;
+        any_nan |= h_nan; any_timeout |= h_to;
         if (naccepted) {
             const int k0 = std::min(i * per, half), nk = std::min(k0 + per, half) - k0;
             for (int hh = 0; hh < 2; ++hh)
@@ -1719,6 +1772,7 @@ int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob,
         }
     }
 #undef MTRY
+    if (any_timeout) { c0->err = "vp_multi_stretch_run: a context gave up waiting for its peers' half-step (in-kernel flags; try the multi_sync = 0 option)"; return finish(multi_fail(m, 0, VP_ESTATE)); }
     if (any_nan) { c0->err = "vp_multi_stretch_run: Probability function returned NaN"; return finish(multi_fail(m, 0, VP_ENAN)); }
     return finish(VP_OK);
 }

@@ -128,11 +128,72 @@ __global__ __launch_bounds__(1024) void stretch_accept_propose_kernel(
 // stores through peer-mapped pointers, (D + 1) doubles per moved walker; the host orders the half-steps with events.
 // The draws are keyed by the walker's index in the whole ensemble, so the chain does not depend on G.
 constexpr int MAX_REPLICAS = 8;
-struct Replicas { double* pos[MAX_REPLICAS]; double* lp[MAX_REPLICAS]; int n; };
+struct Replicas {
+    double* pos[MAX_REPLICAS]; double* lp[MAX_REPLICAS]; int n;
+    // In-kernel ordering of the half-steps (sync != 0) instead of events between the contexts' streams: every replica has
+    // a flag per context, flags[p][g] = the last half-step (1, 2, ... within the call) context g has finished, written by g
+    // into every replica p behind all the rows it moved; the kernels of half-step s start by waiting for every peer's
+    // flag >= s - 1 in their OWN replica.  No kernel waits for a kernel that is queued behind it, so the scheme cannot lock
+    // up as long as the contexts' queues all run.  `done` counts the finished workgroups of the running kernel (reset by the
+    // last one), `timeout` is set when a wait gives up (the host then fails the call instead of hanging the GPU).
+    int* flags[MAX_REPLICAS];
+    unsigned int* done;
+    int* timeout;
+    int me, seq, sync;
+};
+constexpr int SYNC_SPIN_LIMIT = 1 << 22;       // polls (each behind an s_sleep) before a wait gives up: ~ a second
+
+// Scopes: sync == 1 -- all contexts on ONE device -- orders through that device's L2 (agent scope); sync == 2 -- contexts on
+// different devices -- uses system scope, and only the LAST workgroup of a kernel pays the system-scope release (an L2
+// write-back), the others release to the agent ahead of their count (measured on one device with system scope in every
+// workgroup: 48 us per half-step instead of 22).
+// all lanes: wait until every peer has finished half-step R.seq - 1 (their rows in this replica have landed)
+__device__ __forceinline__ void replicas_wait(const Replicas& R) {
+    if (!R.sync || R.seq <= 1 || R.n <= 1) return;
+    const int lane = threadIdx.x & 63;
+    const int need = R.seq - 1;
+    int spins = 0;
+    for (;;) {
+        int f = need;
+        if (lane < R.n && lane != R.me)
+            f = R.sync == 2 ? __hip_atomic_load(R.flags[R.me] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                            : __hip_atomic_load(R.flags[R.me] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(f < need) == 0ull) break;
+        if (++spins > SYNC_SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_store(R.timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    // nothing below is read before the flags were seen
+    if (R.sync == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// one thread per workgroup, behind the workgroup's last store into the replicas: the last workgroup of the grid
+// publishes the half-step to every replica
+__device__ __forceinline__ void replicas_publish(const Replicas& R, unsigned int nworkgroups) {
+    if (!R.sync) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // this workgroup's rows before its count
+    const unsigned int old = __hip_atomic_fetch_add(R.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nworkgroups - 1u) {
+        __hip_atomic_store(R.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (R.sync == 2) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");       // every workgroup's rows, out of this device's L2, before the flags
+            for (int p = 0; p < R.n; ++p)
+                __hip_atomic_store(R.flags[p] + R.me, R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            for (int p = 0; p < R.n; ++p)
+                __hip_atomic_store(R.flags[p] + R.me, R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 __global__ void stretch_propose_block_kernel(const double* __restrict__ pos, int D, int s0, int nS, int c0, int nC, double a,
                                              uint64_t seed, uint64_t step, int half, int k0, int nk,
-                                             double* __restrict__ prop, double* __restrict__ zz) {
+                                             double* __restrict__ prop, double* __restrict__ zz, Replicas R) {
+    replicas_wait(R);                                   // the complementary half as the peers left it
     const int kk = blockIdx.x * blockDim.x + threadIdx.x;
     if (kk >= nk) return;
     (void)nS;
@@ -150,30 +211,43 @@ __global__ void stretch_propose_block_kernel(const double* __restrict__ pos, int
     zz[kk] = z;
 }
 
-// accept / reject of the block (stretch_accept's arithmetic); moved rows go to every replica
-__global__ void stretch_accept_block_kernel(const double* __restrict__ lp_own, Replicas R, const double* __restrict__ prop,
-                                            const double* __restrict__ lp_new, const double* __restrict__ zz, int D, int s0,
-                                            int k0, int nk, uint64_t seed, uint64_t step, int half,
-                                            long long* __restrict__ nacc, int* __restrict__ nanflag) {
+// accept / reject of the block (stretch_accept's arithmetic); moved rows go to every replica, the walker's chain entry
+// (state after this step: every walker is in the active half exactly once per step) to this context's chain buffer
+__global__ void stretch_accept_block_kernel(const double* __restrict__ pos_own, const double* __restrict__ lp_own, Replicas R,
+                                            const double* __restrict__ prop, const double* __restrict__ lp_new,
+                                            const double* __restrict__ zz, int D, int s0, int k0, int nk, uint64_t seed,
+                                            uint64_t step, int half, long long* __restrict__ nacc, int* __restrict__ nanflag,
+                                            double* __restrict__ chain_pos, double* __restrict__ chain_lp) {
     const int kk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (kk >= nk) return;
-    const int w = s0 + k0 + kk;
-    const double ln = lp_new[kk];
-    if (ln != ln) {
-        atomicExch(nanflag, 1);
-        return;
-    }
-    const Philox4 r = draw(seed, step, half, w, 1u);
-    const double u = u01(r.v[0], r.v[1]);
-    const double lnq = (double)(D - 1) * log(zz[kk]) + ln - lp_own[w];
-    if (log(u) < lnq) {
-        const double* __restrict__ y = prop + (size_t)kk * D;
-        for (int rr = 0; rr < R.n; ++rr) {
-            double* __restrict__ x = R.pos[rr] + (size_t)w * D;
-            for (int d = 0; d < D; ++d) x[d] = y[d];
-            R.lp[rr][w] = ln;
+    if (kk < nk) {
+        const int w = s0 + k0 + kk;
+        const double ln = lp_new[kk];
+        bool accept = false;
+        if (ln != ln) {
+            atomicExch(nanflag, 1);
+        } else {
+            const Philox4 r = draw(seed, step, half, w, 1u);
+            const double u = u01(r.v[0], r.v[1]);
+            const double lnq = (double)(D - 1) * log(zz[kk]) + ln - lp_own[w];
+            accept = log(u) < lnq;
         }
-        nacc[w] += 1;
+        const double* __restrict__ y = prop + (size_t)kk * D;
+        if (chain_pos) {                                  // (before the row is overwritten below)
+            for (int d = 0; d < D; ++d) chain_pos[(size_t)w * D + d] = accept ? y[d] : pos_own[(size_t)w * D + d];
+            chain_lp[w] = accept ? ln : lp_own[w];
+        }
+        if (accept) {
+            for (int rr = 0; rr < R.n; ++rr) {
+                double* __restrict__ x = R.pos[rr] + (size_t)w * D;
+                for (int d = 0; d < D; ++d) x[d] = y[d];
+                R.lp[rr][w] = ln;
+            }
+            nacc[w] += 1;
+        }
+    }
+    if (R.sync) {
+        __syncthreads();
+        if (threadIdx.x == 0) replicas_publish(R, gridDim.x);
     }
 }
 

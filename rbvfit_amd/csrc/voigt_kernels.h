@@ -1414,6 +1414,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     // (stretch_propose's arithmetic; every wave repeats the few instructions instead of waiting for one)
     double thv;
     if (SAMPLER) {
+        replicas_wait(S.rep);                    // (sharded ensemble: the complementary half as the peers left it)
         const Philox4 r = draw(S.seed, S.step, S.half, S.s0 + w, 0u);
         const double t = (S.a - 1.0) * u01(r.v[0], r.v[1]) + 1.0;
         const double z = t * t / S.a;
@@ -1535,6 +1536,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             if (lane < A.D) S.chain_pos[(size_t)ws * A.D + lane] = accept ? y : x;
             if (lane == 0) S.chain_lp[ws] = accept ? lnp : lp_old;
         }
+        if (S.rep.n > 0 && S.rep.sync && lane == 0) replicas_publish(S.rep, gridDim.x);
     }
 }
 

@@ -431,12 +431,14 @@ def _multi_for(wl, ids):
     return m
 
 
-@pytest.mark.parametrize("walker", [1, 0])
-def test_sharded_ensemble_reproduces_the_single_context_chain(walker):
+@pytest.mark.parametrize("walker,sync", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_sharded_ensemble_reproduces_the_single_context_chain(walker, sync):
     """vp_multi_stretch_run (BASELINE config 4's shape: ONE ensemble over several device contexts): device 0 listed two
     and three times -- blocks of 13 + 12 and 9 + 9 + 7 rows per half-step, W/2 not divisible by G -- gives the chain of
     vp_stretch_run on one context bit for bit, positions, lnprob, acceptance counts and all, through the one-launch
-    walker kernel (walker = 1) and through propose / lnprob / accept launches (walker = 0); runs can be split into calls."""
+    walker kernel (walker = 1) and through propose / lnprob / accept launches (walker = 0); with the half-steps ordered by
+    flags polled inside the kernels (sync = 1, the default when the contexts share a device) and by events between the
+    contexts' streams (sync = 0); runs can be split into calls."""
     wl = _workload(W=50, pixels=700)
     eng, p0 = wl.engine, wl.thetas
     eng.set_option("walker", walker)
@@ -445,6 +447,7 @@ def test_sharded_ensemble_reproduces_the_single_context_chain(walker):
     for ids in ([0, 0], [0, 0, 0]):
         with _multi_for(wl, ids) as m:
             m.set_option("walker", walker)
+            m.set_option("multi_sync", sync)
             got = m.stretch_run(p0, 24, seed=5)
             for a, b in zip(ref, got):
                 np.testing.assert_array_equal(a, b)
