@@ -795,7 +795,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
                         const double beff = (bl > 0.0 && bu > 0.0) ? std::sqrt(bl * bu) : 20.0;
                         const double dv = ckms * std::fabs(std::log(1.0 / (gc * lam)));
                         ++tot;
-                        if (hwv <= dv / 8.0 && dv - hwv >= vp::FF_XMIN * beff) ++cov;
+                        if (hwv <= dv / 8.0 && dv - hwv >= 30.0 * beff) ++cov;
                     }
                 }
                 in.ff_cover = tot > 0 ? (double)cov / (double)tot : 0.0;
