@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +50,8 @@ struct Tuning {
                                 // half-step; tested with the contexts on ONE device, where it measured no faster than events because the
                                 // contexts' kernels share the CUs (C1, 2 contexts: 49.9 vs 39.5 us per half-step; C3 at 2048 walkers:
                                 // 257 vs 272); across devices it uses system-scope fences and has never run
+    int host_spin = 1;          // host-buffer entries wait for their batch by spinning on a host-mapped completion word the stream writes
+                                // (0: hipStreamSynchronize; measured 512-walker C1 call 42.7 -> ~33 us)
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
 
@@ -61,7 +64,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
-    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0),
+    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -136,6 +139,11 @@ struct vp_ctx {
     int total_tiles_g[2] = {0, 0};
     double* h_pinned = nullptr;  // staging for theta / out
     size_t h_pinned_bytes = 0;
+    // completion of a host-buffer call without an interrupt: the stream writes a sequence number to a host-mapped word
+    // behind the batch (hipStreamWriteValue32), the calling thread spins on it (host_wait)
+    uint32_t* h_done = nullptr;
+    uint32_t done_seq = 0;
+    bool done_armed = false;     // the last batch enqueued carries a completion write
     // model_flux / voigt_h scratch
     double* d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -619,6 +627,7 @@ int vp_ctx_destroy(vp_ctx* c) {
                     (void*)c->d_ff})
         if (p) hipFree(p);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->h_done) hipHostFree(c->h_done);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -899,11 +908,42 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta) {
         if ((rc = enqueue_lnprob(c, W, c->d_theta, c->d_out, c->stream))) return rc;
         HIP_TRY(c, hipMemcpyAsync(h_out, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
     }
+    // completion word behind the batch (the command processor writes it once everything before it on the stream is done
+    // and visible to the host); where the runtime refuses, host_wait falls back to hipStreamSynchronize
+    c->done_armed = false;
+    if (c->tune.host_spin) {
+        if (!c->h_done) {
+            if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocMapped) != hipSuccess) { c->h_done = nullptr; (void)hipGetLastError(); }
+            else *c->h_done = 0;
+        }
+        void* dptr = nullptr;
+        if (c->h_done && hipHostGetDevicePointer(&dptr, c->h_done, 0) == hipSuccess &&
+            hipStreamWriteValue32(c->stream, dptr, ++c->done_seq, 0) == hipSuccess)
+            c->done_armed = true;
+        else
+            (void)hipGetLastError();
+    }
+    return VP_OK;
+}
+// wait for the batch lnprob_host_begin enqueued: spin on the completion word (no interrupt, no driver call on the way),
+// hipStreamSynchronize when the word is not armed or has not come after 20 ms (a long batch: the interrupt is cheap then)
+static int host_wait(vp_ctx* c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->done_armed) {
+        const uint32_t want = c->done_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned int spins = 0;; ++spins) {
+            if (__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) == want) return VP_OK;
+            __builtin_ia32_pause();
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VP_OK;
 }
 static int lnprob_host_end(vp_ctx* c, int W, int D, double* out) {
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = host_wait(c))) return rc;
     std::memcpy(out, c->h_pinned + (size_t)W * D, (size_t)W * sizeof(double));
     return VP_OK;
 }
@@ -1534,9 +1574,7 @@ int vp_multi_lnprob_batch(vp_multi* m, int W, int D, const double* theta, double
     for (int i = 0; i < G; ++i) {
         if (!begun[i]) continue;
         vp_ctx* c = m->ctx[i];
-        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
-            if (!rc) { c->err = "hipStreamSynchronize failed"; rc = multi_fail(m, i, VP_EHIP); }
-        }
+        if (host_wait(c) != VP_OK && !rc) rc = multi_fail(m, i, VP_EHIP);
     }
     if (rc) return rc;
     for (int i = 0; i < G; ++i) {
