@@ -459,7 +459,7 @@ def rank_main(args):
                 wl.engine.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
                 sampler_steps = nst / (time.perf_counter() - ts0)
                 # and the reference's second sampler (zeus' ensemble slice sampling) with the walker loop on the GPU
-                if W <= 2048:
+                if W <= 4096:
                     nsl = 60 if args.config in ("C0", "C1") else 6
                     r0 = wl.engine.slice_run(wl.thetas, max(2, nsl // 6), seed=1, store_chain=False)
                     ts0 = time.perf_counter()

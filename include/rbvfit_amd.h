@@ -144,7 +144,7 @@ int vp_stretch_run(vp_ctx* ctx, int W, int D, double* pos, double* lnprob, int h
  * round is one lnprob batch of slice_rows * W/2 rows ("slice_rows" option, 2 ... 8, default 2: W rows -- the next 2 ... 8
  * trial points of every active walker first, the rest prior-rejected filler), and the host only reads one word per
  * group of rounds to learn whether the half-step is finished.
- *   pos, lnprob, have_lnprob, seed, step0, chain, chain_lnprob: as in vp_stretch_run.  W even, 4 <= W <= 2048.
+ *   pos, lnprob, have_lnprob, seed, step0, chain, chain_lnprob: as in vp_stretch_run.  W even, 4 <= W <= 4096.
  *   mu         in: initial scale (zeus: 1.0), out: scale after the run.
  *   tune       != 0: adapt mu after every iteration (mu *= 2 n_expansions / (n_expansions + n_contractions)),
  *              and stop adapting after `patience` consecutive iterations with |ratio - 1| < tolerance

@@ -1239,7 +1239,7 @@ static int slice_run_impl(vp_multi* m, vp_ctx* const* cx, int G, int W, int D, d
     auto done_ = [&](int code) { for (int i = 0; i < G; ++i) cx[i]->policy_W = 0; return code; };
     if (G > 1 && (rc = multi_barrier(m))) return done_(rc);
     const double gamma0 = 2.38 / std::sqrt(2.0 * (double)D);
-    const int thr = ((half + 63) / 64) * 64;
+    const int thr = std::min(1024, ((half + 63) / 64) * 64);        // (beyond 1024 walkers per half a thread looks after two)
     int group = 6;                                   // rounds enqueued before the host looks at n_active (adapts to the run)
     // one round: the lnprob of the B trial rows (sharded when G > 1), then the update kernel on every replica
     auto round = [&](int h, uint64_t step) -> int {

@@ -29,7 +29,8 @@
 namespace vp {
 
 constexpr int SL_OUT = 0, SL_SHRINK = 2, SL_DONE = 3;
-constexpr int SLICE_MAX_HALF = 1024;    // one workgroup handles a half-ensemble (W <= 2048)
+constexpr int SLICE_MAX_HALF = 2048;    // one workgroup of <= 1024 threads handles a half-ensemble, up to SLICE_KPT walkers per thread (W <= 4096)
+constexpr int SLICE_KPT = 2;
 constexpr int SLICE_MAXC = 8;           // candidates a walker may have in one round
 
 struct SliceState {          // per walker-slot k of the active half (device arrays of length half)
@@ -89,19 +90,31 @@ __device__ inline int block_scan01(bool flag, int* lds_counts, int* total) {
 // point, the brackets, the expansion / contraction counts (hence mu) and the count of evaluations are exactly those
 // of the one-evaluation-at-a-time procedure; speculation only buys rounds (latency) with throughput.
 // Rows of invalid candidates and of DONE walkers hold +inf, which the box prior rejects without evaluating the model.
-__device__ inline void slice_emit(int k, int half, const SliceState& st, int D, int batch_rows, uint64_t seed, uint64_t step,
+__device__ inline void slice_emit(int half, const SliceState& st, int D, int batch_rows, uint64_t seed, uint64_t step,
                                   int h, double* __restrict__ trial, const SliceCounters& cn, int* lds_counts) {
-    const bool active = k < half && st.phase[k] != SL_DONE;
-    for (int r = k; r < batch_rows; r += blockDim.x) {
+    // thread t looks after the walkers k = t, t + blockDim, ...: their ranks among the active ones run through the
+    // passes in that order (rank = active walkers with a smaller k)
+    bool active[SLICE_KPT];
+    int a[SLICE_KPT], total = 0;
+    for (int r = threadIdx.x; r < batch_rows; r += blockDim.x) {
         double* row = trial + (size_t)r * D;
         for (int d = 0; d < D; ++d) row[d] = __builtin_inf();
     }
-    int total;
-    const int a = block_scan01(active, lds_counts, &total);       // (contains barriers: the filler is complete behind it)
+#pragma unroll
+    for (int p = 0; p < SLICE_KPT; ++p) {
+        const int k = threadIdx.x + p * blockDim.x;
+        active[p] = k < half && st.phase[k] != SL_DONE;
+        int tp;
+        a[p] = total + block_scan01(active[p], lds_counts, &tp);   // (contains barriers: the filler is complete behind it)
+        total += tp;
+    }
     int nc = total > 0 ? (batch_rows / total) & ~1 : 2;
     nc = nc < 2 ? 2 : (nc > SLICE_MAXC ? SLICE_MAXC : nc);
-    if (k < half) st.row[k] = active ? a : -1;
-    if (active) {
+#pragma unroll
+    for (int p = 0; p < SLICE_KPT; ++p) {
+        const int k = threadIdx.x + p * blockDim.x;
+        if (k < half) st.row[k] = active[p] ? a[p] : -1;
+        if (!active[p]) continue;
         double* T = st.T + (size_t)k * SLICE_MAXC;
         bool valid[SLICE_MAXC];
         if (st.phase[k] == SL_OUT) {
@@ -133,7 +146,7 @@ __device__ inline void slice_emit(int k, int half, const SliceState& st, int D, 
 #pragma unroll
         for (int s = 0; s < SLICE_MAXC; ++s) {
             if (s < nc && valid[s]) {
-                double* row = trial + ((size_t)a * nc + s) * D;
+                double* row = trial + ((size_t)a[p] * nc + s) * D;
                 const double t = T[s];
                 for (int d = 0; d < D; ++d) row[d] = x0[d] + t * e[d];
             }
@@ -194,8 +207,7 @@ __global__ __launch_bounds__(1024) void slice_init_kernel(const double* __restri
                                                           int batch_rows, SliceState st, SliceCounters cn,
                                                           double* __restrict__ trial) {
     __shared__ int lds_counts[16];
-    const int k = threadIdx.x;
-    if (k < half) {
+    for (int k = threadIdx.x; k < half; k += blockDim.x) {
         const int* S = perm + h * half;
         const int* C = perm + (1 - h) * half;
         const int w = S[k];
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(1024) void slice_init_kernel(const double* __restri
         st.phase[k] = sd == 3 ? SL_SHRINK : SL_OUT;
         st.nshr[k] = 0;
     }
-    slice_emit(k, half, st, D, batch_rows, seed, step, h, trial, cn, lds_counts);
+    slice_emit(half, st, D, batch_rows, seed, step, h, trial, cn, lds_counts);
 }
 
 // After a round's lnprob batch: every walker that is not DONE consumes the results of its candidates in order, up to
@@ -240,11 +252,11 @@ __global__ __launch_bounds__(1024) void slice_update_kernel(double* __restrict__
                                                             SliceCounters cn, double* __restrict__ trial) {
     __shared__ int lds_counts[16];
     __shared__ int s_exp, s_con, s_ev;
-    const int k = threadIdx.x;
-    if (k == 0) { s_exp = 0; s_con = 0; s_ev = 0; }
+    if (threadIdx.x == 0) { s_exp = 0; s_con = 0; s_ev = 0; }
     __syncthreads();
     const int nc = *cn.ncand;
-    if (k < half && st.row[k] >= 0) {
+    for (int k = threadIdx.x; k < half; k += blockDim.x) {
+        if (st.row[k] < 0) continue;
         const double* res = lnp_rows + (size_t)st.row[k] * nc;
         const double* T = st.T + (size_t)k * SLICE_MAXC;
         const double z0 = st.Z0[k];
@@ -298,8 +310,8 @@ __global__ __launch_bounds__(1024) void slice_update_kernel(double* __restrict__
         atomicAdd(&s_ev, nev); atomicAdd(&s_exp, nex); atomicAdd(&s_con, nco);
     }
     __syncthreads();
-    if (k == 0) { *cn.nexp += s_exp; *cn.ncon += s_con; *cn.n_evals += s_ev; }
-    slice_emit(k, half, st, D, batch_rows, seed, step, h, trial, cn, lds_counts);
+    if (threadIdx.x == 0) { *cn.nexp += s_exp; *cn.ncon += s_con; *cn.n_evals += s_ev; }
+    slice_emit(half, st, D, batch_rows, seed, step, h, trial, cn, lds_counts);
 }
 
 }  // namespace vp

@@ -345,7 +345,7 @@ def _replay_slice(lnprob, p0, nsteps, seed, mu=1.0, tune=True, tolerance=0.05, p
     return dict(pos=pos, lnprob=lp, chain=chain, chain_lnprob=clp, mu=mu, tune=tune, mu_history=hist, n_evals=n_evals)
 
 
-@pytest.mark.parametrize("W,nsteps", [(16, 12), (48, 25)])
+@pytest.mark.parametrize("W,nsteps", [(16, 12), (48, 25), (2600, 6)])     # (2600: 1300 walkers per half, two per thread of the control kernels)
 def test_device_slice_sampler_equals_an_independent_host_replay(W, nsteps):
     """N1, second move: vp_slice_run against a NumPy restatement that shares only Engine.lnprob and the Philox
     function -- chain, stored lnprob, mu trajectory and the number of lnprob evaluations must be identical, also
