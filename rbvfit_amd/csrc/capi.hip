@@ -52,6 +52,7 @@ struct Tuning {
                                 // 257 vs 272); across devices it uses system-scope fences and has never run
     int host_spin = 1;          // host-buffer entries wait for their batch by spinning on a host-mapped completion word the stream writes
                                 // (0: hipStreamSynchronize; measured 512-walker C1 call 42.7 -> ~33 us)
+    int no_ff_members = 0;      // (read when an instrument is added) never take cluster members into the far-field expansions one by one
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
 
@@ -64,7 +65,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
-    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
+    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -500,7 +501,8 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             vp::InstDev g2 = geom;
             g2.ff = ff;
             const int nbk = geom.ntiles * geom.ff_nblk;
-            hipLaunchKernelGGL(vp::farfield_kernel, dim3((nbk + 63) / 64, W), dim3(64), 0, s, g2, in.lines, c->d_lc, W);
+            if (g2.ff_members) hipLaunchKernelGGL((vp::farfield_kernel<9, true>), dim3((nbk + 63) / 64, W), dim3(64), 0, s, g2, in.lines, c->d_lc, W);
+            else hipLaunchKernelGGL((vp::farfield_kernel<6, false>), dim3((nbk + 63) / 64, W), dim3(64), 0, s, g2, in.lines, c->d_lc, W);
         }
         size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin,
@@ -755,7 +757,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         if ((rc = upload<int>(c, &in, zeros.data(), zeros.size(), &d_hint))) { for (void* p : in.allocs) hipFree(p); return rc; }
         d.core_hint = d_hint;
     }
-    d.ff_tab = nullptr; d.ff = nullptr; d.ff_nblk = 0;
+    d.ff_tab = nullptr; d.ff = nullptr; d.ff_nblk = 0; d.ff_members = 0;
     in.dev_s = d;                                        // one-pass tiles for small batches (same LDS layout rules)
     {
         const int span_s = 64 * vp::RB * nwaves;
@@ -809,6 +811,24 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
                 }
                 in.ff_cover = tot > 0 ? (double)cov / (double)tot : 0.0;
                 {
+                    // members of near clusters line by line (farfield_kernel): only where a block is narrow against the
+                    // lines -- half-width <= 1/8 of a distance of ~30 Doppler widths of the narrowest line allowed
+                    std::vector<double> hwvs;
+                    for (size_t bk = 0; bk < tab.size() / 4; ++bk)
+                        if (tab[4 * bk + 1] >= 0.0 && tab[4 * bk] > 0.0) hwvs.push_back(ckms * tab[4 * bk + 1] / tab[4 * bk]);
+                    double bmin = 1e300;
+                    for (int l = 0; l < L; ++l) {
+                        const double bl = c->h_lb[b_idx[l]], bu = c->h_ub.size() == c->h_lb.size() ? c->h_ub[b_idx[l]] : bl;
+                        bmin = std::min(bmin, (bl > 0.0 && bu > 0.0) ? std::sqrt(bl * bu) : 20.0);
+                    }
+                    int members = 0;
+                    if (!hwvs.empty() && NCm > 0 && !c->tune.no_ff_members) {
+                        std::nth_element(hwvs.begin(), hwvs.begin() + hwvs.size() / 2, hwvs.end());
+                        members = hwvs[hwvs.size() / 2] <= (30.0 / 8.0) * bmin ? 1 : 0;
+                    }
+                    in.dev.ff_members = members;
+                }
+                {
                     int members = 0;
                     for (size_t k = 0; k < cl_count.size(); ++k) members += cl_count[k];
                     in.ff_items = (int)cl_count.size() + (L - members);
@@ -818,6 +838,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
             }
         }
     }
+    in.dev_s.ff_members = in.dev.ff_members;
     in.lds_bytes = (size_t)(span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + vp::EXP_LDS_DOUBLES + (span / 64) * ((L + 63) / 64)) * sizeof(double);
     {
         in.dev_w = in.dev;

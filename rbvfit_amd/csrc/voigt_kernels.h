@@ -82,6 +82,8 @@ struct InstDev {
     const double* ff_tab;
     double* ff;
     int ff_nblk;           // blocks per tile = ceil(span / (64 RB))
+    int ff_members;        // 1: members of clusters too near for their multipole may enter a block's expansion line by line (spectra
+                           // whose blocks are a few Doppler widths wide: C4; pointless, and a little slower, on coarse grids)
     int* core_hint;        // (16) walker_kernel: tile t met line cores in an earlier launch -> its wave stages the Dawson
                            // table while it waits for the records instead of between phase A and phase B (a hint only:
                            // results never depend on it)
@@ -419,7 +421,13 @@ __device__ __forceinline__ double line_tau_fast(const XP& xp, rec_t rec, const d
 // those lines together and walks only the others (C2: 19 lines, of which 15-19 are far from most blocks).  Members of
 // a multipole cluster go in together or not at all, so that the cluster's own expansion never counts a line twice.
 constexpr int FF_NC = 12, FF_STRIDE = 16, FF_MASK0 = 12;      // per (walker, block): c_0..c_11 | 2 mask words | pad
-constexpr int FF_M = 6;
+constexpr int FF_M = 9;            // asymptotic terms a line's expansion can carry (rows of the table below).  farfield_kernel<M>: 6 terms
+                                   // serve blocks with every |x| >= 30; 9 serve |x| >= 14 (the tile kernel's own tiers) and are used where
+                                   // the blocks are narrow enough for that band to matter (InstDev::ff_members: C4 -17 % per pass, C2 / C3 +1 %
+                                   // if they carried them)
+#ifndef VP_FF_MIN_LANES
+#define VP_FF_MIN_LANES 4
+#endif
 struct FFTable { double b[FF_M][FF_NC]; };
 constexpr FFTable make_ff_table() {
     FFTable t{};
@@ -467,7 +475,9 @@ __device__ __forceinline__ void ff_cluster_accum(const double (&pq)[FF_KMAX], do
     }
 }
 
+template <int M, bool MEMBERS>      // MEMBERS: cluster members may be taken line by line (InstDev::ff_members); the plain instance is free of it
 __global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, const double* __restrict__ lc, int W) {
+    constexpr double XMIN = M >= 9 ? 14.0 : 30.0;
     // one wave = 64 blocks of ONE walker (grid.y): the walker's records, the cluster tables and all the bookkeeping on
     // them are wave-uniform (scalar loads, scalar ALU); per lane only the block's own numbers
     const int nb = I.ntiles * I.ff_nblk;
@@ -482,6 +492,11 @@ __global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, con
 #pragma unroll
     for (int j = 0; j < FF_NC; ++j) c[j] = 0.0;
     unsigned long long mask[2] = {0ull, 0ull}, member[2] = {0ull, 0ull};
+    // members of clusters that lie so NEAR this block that the tile kernel cannot use the cluster's multipole anywhere in it
+    // (every pixel inside the nearest tier's radius): there the tile kernel walks the members one by one, and the far ones
+    // among them -- most of a cluster of narrow and wide components -- can go into the block's expansion line by line.
+    // solo: per lane (block); visit: members some lane of the wave may take (wave-uniform)
+    unsigned long long solo[2] = {0ull, 0ull}, visit[2] = {0ull, 0ull};
     const bool live = hw >= 0.0 && T.L <= 128;                  // (hw < 0: the block holds no pixel)
     // ---- clusters: the multipole series of the whole cluster, where the block lies in one of its far tiers; its
     //      member lines are then covered together (and never one by one: the cluster's own expansion in the tile
@@ -501,6 +516,13 @@ __global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, con
         const double yc = __builtin_fma(Ac, gc, -Bc), ayc = fabs(yc), hwy = fabs(Ac) * hw, ynear = ayc - hwy;
         int J = ynear >= mrec[MP_Y0 + 4] ? MP_J4 : (ynear >= mrec[MP_Y0 + 3] ? MP_J3 : (ynear >= mrec[MP_Y0 + 2] ? MP_J2 :
                 (ynear >= mrec[MP_Y0 + 1] ? MP_J1 : 0)));
+        {
+            // (the tile kernel uses the multipole of a pass only if EVERY pixel has |y| >= Y_0: with the block's farthest
+            //  pixel inside that radius -- a hair inside, for the roundings of y -- it cannot, whatever the pass looks like)
+            const bool inside = MEMBERS && live && (ayc + hwy) * (1.0 + 1e-9) < mrec[MP_Y0];
+            if (inside) { solo[0] |= rm[0]; solo[1] |= rm[1]; }
+            if (__ballot(inside) != 0ull) { visit[0] |= rm[0]; visit[1] |= rm[1]; }
+        }
         bool ok = live && J > 0 && hwy <= 0.125 * ayc;
         const double iyc = fast_rcp(yc);
         if (ok) {
@@ -522,33 +544,40 @@ __global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, con
             if (J > 0) { mask[0] |= rm[0]; mask[1] |= rm[1]; }
         }
     }
-    // ---- the other lines one by one
+    // ---- the other lines one by one (and the members of clusters too near for their multipole, see above)
     for (int l = 0; l < T.L; ++l) {
-        if ((member[l >> 6] >> (l & 63)) & 1ull) continue;
+        const bool is_member = (member[l >> 6] >> (l & 63)) & 1ull;
+        if (is_member && !(MEMBERS && ((visit[l >> 6] >> (l & 63)) & 1ull))) continue;
+        const bool mine = !MEMBERS || !is_member || ((solo[l >> 6] >> (l & 63)) & 1ull);     // (per lane)
         rec_t rec = recs + (size_t)l * LC_STRIDE;
-        double Kl[FF_M];
+        double Kl[M];
 #pragma unroll
-        for (int mm = 0; mm < FF_M; ++mm) Kl[mm] = rec[LC_K0 + mm];
+        for (int mm = 0; mm < M; ++mm) Kl[mm] = rec[LC_K0 + mm];
         const double A = rec[LC_A], B = rec[LC_B], K0 = Kl[0];
         const int mode = rec_int(rec, LC_MODE, 0);
         const double xc = __builtin_fma(A, gc, -B), axc = fabs(xc), hwx = fabs(A) * hw;
-        bool ok = live && mode == 0 && (axc - hwx >= 30.0) && (hwx <= 0.125 * axc);
+        bool ok = live && mine && mode == 0 && (axc - hwx >= XMIN) && (hwx <= 0.125 * axc);
         const double ixc = fast_rcp(xc), sc = ixc * ixc;
         if (ok) {
             const double rho = hwx * fabs(ixc), r2 = rho * rho, r4 = r2 * r2, r12 = r4 * r4 * r4, om = 1.0 - rho;
             ok = fabs(K0) * sc * 13.0 * r12 <= 1e-16 * (om * om);      // (NaN: not ok)
         }
-        if (__ballot(ok) == 0ull) continue;
-        double q[FF_M], sp = sc;
+        {
+            // an item costs the wave ~150 instructions whatever the number of blocks that take it, a covered (block, line)
+            // saves the tile kernel ~50: members of near clusters only where at least VP_MIN_LANES blocks want them
+            const int nok = __builtin_popcountll(__ballot(ok));
+            if (nok == 0 || (MEMBERS && is_member && nok < VP_FF_MIN_LANES)) continue;
+        }
+        double q[M], sp = sc;
 #pragma unroll
-        for (int mm = 0; mm < FF_M; ++mm) { q[mm] = ok ? Kl[mm] * sp : 0.0; sp *= sc; }
+        for (int mm = 0; mm < M; ++mm) { q[mm] = ok ? Kl[mm] * sp : 0.0; sp *= sc; }
         const double r = ok ? (A * hw) * ixc : 0.0;
         double rj = 1.0;
 #pragma unroll
         for (int j = 0; j < FF_NC; ++j) {
-            double inner = q[FF_M - 1] * g_ff.b[FF_M - 1][j];
+            double inner = q[M - 1] * g_ff.b[M - 1][j];
 #pragma unroll
-            for (int mm = FF_M - 2; mm >= 0; --mm) inner = __builtin_fma(q[mm], g_ff.b[mm][j], inner);
+            for (int mm = M - 2; mm >= 0; --mm) inner = __builtin_fma(q[mm], g_ff.b[mm][j], inner);
             c[j] = __builtin_fma(inner, rj, c[j]);
             rj *= r;
         }
