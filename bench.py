@@ -222,6 +222,12 @@ def rank_main(args):
         pool_cores = min(16, len(os.sched_getaffinity(0)))
         pool = mp.get_context("fork").Pool(pool_cores)
 
+    # the library (and the oracle's C restatement) is built -- compilers are child processes -- BEFORE this process touches
+    # the GPU: a process that has initialised it must not start other programs on these boxes
+    if int(os.environ.get("RANK", "0")) == 0:
+        import __graft_entry__ as ge
+        ge.build()
+
     import torch
     import torch.distributed as dist
 
@@ -241,11 +247,8 @@ def rank_main(args):
             os.environ.setdefault(k, v)            # only matters for a BENCH_FORCE_DIST=1 run without torchrun
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
     if use_dist:
-        dist.barrier()
+        dist.barrier()                             # (rank 0 built the library before it touched the GPU, see above)
     from rbvfit_amd.workloads import make_workload
 
     # walkers per rank: weak = the config's per-GPU share whatever N; strong = its total split W/N
