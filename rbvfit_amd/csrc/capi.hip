@@ -53,6 +53,7 @@ struct Tuning {
     int host_spin = 1;          // host-buffer entries wait for their batch by spinning on a host-mapped completion word the stream writes
                                 // (0: hipStreamSynchronize; measured 512-walker C1 call 42.7 -> ~33 us)
     int no_ff_members = 0;      // (read when an instrument is added) never take cluster members into the far-field expansions one by one
+    int tile_multi = -1;        // tiles of several instruments in one launch (tile_kernel_multi): -1 by batch size, 0 never, 1 whenever possible
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
 
@@ -65,7 +66,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_zerocopy, "RBVFIT_AMD_NO_ZEROCOPY", 0), VP_KNOB(no_multipole, "RBVFIT_AMD_NO_MULTIPOLE", 0), VP_KNOB(multipole_min, "RBVFIT_AMD_MULTIPOLE_MIN", 0),
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
-    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
+    VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -138,6 +139,7 @@ struct vp_ctx {
     bool meta_dirty = true;
     int total_tiles = 0;         // max over the two geometries (workspace size)
     int total_tiles_g[2] = {0, 0};
+    int total_tiles_w = 0;       // tiles of all instruments in the single-wave geometry (tile_kernel_multi)
     double* h_pinned = nullptr;  // staging for theta / out
     size_t h_pinned_bytes = 0;
     // completion of a host-buffer call without an interrupt: the stream writes a sequence number to a host-mapped word
@@ -225,16 +227,18 @@ int ensure_workspace(vp_ctx* c, int W) {
     for (auto& in : c->inst) maxL = std::max(maxL, in.dev.L + in.dev.NCm);
     if (c->meta_dirty) {
         const size_t n1 = c->inst.size() + 1;
-        std::vector<int> off(2 * n1, 0);
+        std::vector<int> off(3 * n1, 0);                   // full-size | one-pass | single-wave (dev_w) geometry
         std::vector<double> slw(n1, 0.0);
         for (size_t k = 0; k < c->inst.size(); ++k) {
             off[k + 1] = off[k] + c->inst[k].dev.ntiles;
             off[n1 + k + 1] = off[n1 + k] + c->inst[k].dev_s.ntiles;
+            off[2 * n1 + k + 1] = off[2 * n1 + k] + c->inst[k].dev_w.ntiles;
             slw[k] = c->inst[k].sum_logw;
         }
         c->total_tiles_g[0] = off[n1 - 1];
         c->total_tiles_g[1] = off[2 * n1 - 1];
-        c->total_tiles = std::max(c->total_tiles_g[0], c->total_tiles_g[1]);
+        c->total_tiles_w = off[3 * n1 - 1];
+        c->total_tiles = std::max({c->total_tiles_g[0], c->total_tiles_g[1], c->total_tiles_w});
         if (c->d_tile_off) HIP_TRY(c, hipFree(c->d_tile_off));
         if (c->d_sum_logw) HIP_TRY(c, hipFree(c->d_sum_logw));
         HIP_TRY(c, hipMalloc((void**)&c->d_tile_off, off.size() * sizeof(int)));
@@ -477,6 +481,59 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     const bool fused = fmode != 0;
     const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw,
                                d_out, (int)c->inst.size(), ntot, fmode};
+    // ---- several instruments with one set of records, small batch: all their tiles in ONE launch (tile_kernel_multi)
+    {
+        const size_t ni = c->inst.size();
+        bool multi = !prof && ni >= 2 && ni <= 4 && c->tune.tile_multi != 0 && !c->tune.no_shared_prep;
+        size_t lds = 0;
+        long waves = 0;
+        for (size_t k = 0; multi && k < ni; ++k) {
+            const Instrument& in = c->inst[k];
+            if (k > 0 && !in.same_lines_as_prev) multi = false;
+            if (in.lds_w == 0 || in.dev.method != c->inst[0].dev.method) multi = false;
+            if (in.needs_generic && in.dev.method == VP_VOIGT_WOFZ) multi = false;
+            lds = std::max(lds, in.lds_w);
+            waves += (long)Wp * in.dev_w.ntiles;
+        }
+        // (measured on C3, two instruments of 8192 pixels = 52 single-wave tiles per walker, us per pass, launches / one launch:
+        //  64 walkers 67.5 / 56.7, 256: 89.2 / 92.5, 512: 143.1 / 143.9, 1024: 229 / 251, 2048: 401 / 468 -- the long LSF's tiles carry
+        //  more halo as single waves, which only a batch that leaves the GPU mostly idle does not feel)
+        if (multi && c->tune.tile_multi < 0 && waves > 6144) multi = false;
+        if (multi) {
+            c->last_kind = 3;
+            const Instrument& in0 = c->inst[0];
+            if (prof) (void)0;
+            launch_prep(c, in0, d_theta, W, 1, d_out, (int*)nullptr, s);
+            vp::InstDev dk[4] = {in0.dev_w, in0.dev_w, in0.dev_w, in0.dev_w};
+            vp::TileMulti tb{};
+            int tsum = 0;
+            for (size_t k = 0; k < ni; ++k) {
+                dk[k] = c->inst[k].dev_w;
+                tb.off[k] = tsum;
+                if (k > 0) tb.t[k - 1] = tsum;
+                tsum += dk[k].ntiles;
+            }
+            for (size_t k = ni; k < 4; ++k) { tb.t[k - 1] = tsum; tb.off[k] = tsum; }
+            const int nt = c->total_tiles_w;
+            int fm = ((long)Wp * nt < 6144) ? 1 : 0;
+            if (c->tune.finalize >= 0) fm = c->tune.finalize ? 1 : 0;
+            const vp::FinalizeArgs fw{c->d_ticket, c->d_tile_off + 2 * (ni + 1), c->d_sum_logw, d_out, (int)ni, nt, fm};
+            const dim3 grid(W, nt), block(64);
+            if (in0.dev.method == VP_VOIGT_FAST)
+                hipLaunchKernelGGL((vp::tile_kernel_multi<1>), grid, block, lds, s, dk[0], dk[1], dk[2], dk[3], tb, (int)ni, c->d_lc, c->d_flags, c->d_partial, nt, fw);
+            else
+                hipLaunchKernelGGL((vp::tile_kernel_multi<0>), grid, block, lds, s, dk[0], dk[1], dk[2], dk[3], tb, (int)ni, c->d_lc, c->d_flags, c->d_partial, nt, fw);
+            if (!fm) {
+                vp::FinalizeByValue bv{};
+                bv.n_inst = (int)ni;
+                for (size_t k = 0; k < ni; ++k) { bv.tile_off[k] = tb.off[k]; bv.sum_logw[k] = c->inst[k].sum_logw; }
+                bv.tile_off[ni] = nt;
+                hipLaunchKernelGGL((vp::finalize_kernel<true>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, nt, W, c->d_flags, fw, bv);
+            }
+            HIP_TRY(c, hipGetLastError());
+            return VP_OK;
+        }
+    }
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
@@ -595,7 +652,7 @@ int vp_ctx_create(vp_ctx** out, int device_id) {
                           (const void*)vp::walker_kernel2<1, false>, (const void*)vp::walker_kernel2<1, true>,
                           (const void*)vp::walker_kernel4<0, false>, (const void*)vp::walker_kernel4<0, true>,
                           (const void*)vp::walker_kernel4<1, false>, (const void*)vp::walker_kernel4<1, true>,
-                          (const void*)vp::tile_kernel<0, 0, false, true>,
+                          (const void*)vp::tile_kernel<0, 0, false, true>, (const void*)vp::tile_kernel_multi<0>, (const void*)vp::tile_kernel_multi<1>,
                           (const void*)vp::tile_kernel<0, 0, false>, (const void*)vp::tile_kernel<0, 0, true>,
                           (const void*)vp::tile_kernel<0, 1, false>, (const void*)vp::tile_kernel<0, 1, true>,
                           (const void*)vp::tile_kernel<0, 2, false>, (const void*)vp::tile_kernel<0, 2, true>,

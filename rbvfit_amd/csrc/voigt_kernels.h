@@ -1307,6 +1307,32 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(Ins
     }
 }
 
+// Tiles of up to four instruments in ONE launch (instruments of a joint fit that share their records -- same line tables --
+// each in walker_kernel's geometry: single-wave tiles whatever the LSF length): grid (W, all tiles), tile t belongs to
+// instrument k = the one whose first tile tb.t[k-1] <= t.  For batches too small to fill the GPU with one instrument's
+// tiles -- C3's per-GPU share of 256 walkers spent 2 x 36 us in two launches that each left most CUs idle; running them
+// on two streams costs more in cross-queue waits than it saves (profiles/r03_notes.md).  Same tile work, same slots of the
+// partial sums, same final reduction as the per-instrument launches (the LSFs of more than 33 taps get more halo per tile).
+struct TileMulti { int t[3]; int off[4]; };     // first grid tile of instruments 1..3; first slot of each instrument's partial sums
+template <int METHOD>
+__global__ __launch_bounds__(64, VP_TILE_WPE) void tile_kernel_multi(InstDev I0, InstDev I1, InstDev I2, InstDev I3, TileMulti tb, int ninst,
+                                                                     const double* __restrict__ lc, const int* __restrict__ flags,
+                                                                     double* __restrict__ out, int out_stride, FinalizeArgs F) {
+    extern __shared__ double fl[];
+    const int t = blockIdx.y, w = blockIdx.x;
+    const int ki = (ninst > 1 && t >= tb.t[0]) ? ((ninst > 2 && t >= tb.t[1]) ? ((ninst > 3 && t >= tb.t[2]) ? 3 : 2) : 1) : 0;
+    const InstDev& I = ki == 0 ? I0 : (ki == 1 ? I1 : (ki == 2 ? I2 : I3));
+    const int lt = ki == 0 ? t : t - tb.t[ki - 1];
+    const int oob = flags[w];
+    const int p0 = lt * I.TP, nout = min(p0 + I.TP, I.P) - p0;
+    const TilePre pre = tile_preload(I, p0, nout, threadIdx.x);
+    if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
+    rec_t lcw = as_rec(lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE);
+    const double wsum = wave_sum(tile_work<METHOD, 0, false, false>(I, lcw, fl, p0, nout, w, threadIdx.x, 64, pre, true, out, out_stride VP_STAMP_NONE,
+                                                                   false, lt));
+    if (threadIdx.x == 0) publish_partial(F, out, out_stride, w, tb.off[ki] + lt, wsum);
+}
+
 // ---------------------------------------------------------------------------------------------
 // walker kernel: the whole lnprob of one walker in ONE workgroup, one launch per batch
 // ---------------------------------------------------------------------------------------------

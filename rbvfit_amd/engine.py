@@ -273,10 +273,11 @@ class Engine:
     @property
     def last_launch_kind(self) -> str:
         """'walker' when the last lnprob batch ran as ONE walker_kernel launch, 'tiles' for prep + tile (+ finalize)
-        launches, 'tiles+farfield' when those took far lines from per-block expansions (farfield_kernel)."""
+        launches, 'tiles+farfield' when those took far lines from per-block expansions (farfield_kernel), 'tiles-multi' when the
+        tiles of several instruments that share their records ran as one launch (tile_kernel_multi)."""
         self._guard()
         kind = self._lib.vp_last_launch_kind(self._ctx)
-        return "walker" if kind == 1 else ("tiles+farfield" if kind == 2 else "tiles")
+        return {1: "walker", 2: "tiles+farfield", 3: "tiles-multi"}.get(kind, "tiles")
 
     # -- per-kernel timing (HIP events on the launch stream) ------------------------------------
     def profile_enable(self, on: bool = True):

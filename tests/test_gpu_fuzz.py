@@ -269,9 +269,18 @@ def test_several_instruments_in_one_walker_launch(n_inst):
             e.add_instrument(wave, flux, oi.inv_sigma2, oi.log_inv_sigma2, **data.engine_kwargs())
         got = e.lnprob(thetas)
         assert e.last_launch_kind == "walker"
-        e.set_option("walker", 0); e.set_option("geom", 0); e.set_option("finalize", 0)
+        e.set_option("walker", 0); e.set_option("geom", 0); e.set_option("finalize", 0); e.set_option("tile_multi", 0)
         launches = e.lnprob(thetas)
         assert e.last_launch_kind == "tiles"
+        # ... and with the tiles of all the instruments in one launch (tile_kernel_multi), final reduction by launch and by ticket
+        e.set_option("tile_multi", 1)
+        one = e.lnprob(thetas)
+        assert e.last_launch_kind == "tiles-multi"
+        np.testing.assert_array_equal(one, launches)
+        e.set_option("finalize", 1)
+        np.testing.assert_array_equal(e.lnprob(thetas), launches)
+        assert e.last_launch_kind == "tiles-multi"
+        e.set_option("finalize", 0); e.set_option("tile_multi", -1)
         e.set_option("walker", -1)
         pos, lp, chain, clp, nacc = e.stretch_run(thetas[:32], 12, seed=4)        # half-steps as one launch each
         e.set_option("geom", 0)
