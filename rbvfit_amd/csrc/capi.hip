@@ -1260,7 +1260,7 @@ static int slice_run_impl(vp_multi* m, vp_ctx* const* cx, int G, int W, int D, d
         SFAIL(0, VP_EINVAL, "vp_slice_run: nsteps >= 0, mu > 0, maxsteps >= 1, patience >= 1, tolerance >= 0 and non-NULL mu/tune required");
     if ((chain == nullptr) != (chain_lnprob == nullptr)) SFAIL(0, VP_EINVAL, "vp_slice_run: chain and chain_lnprob go together");
     const int half = W / 2;
-    const int B = std::max(2, std::min(vp::SLICE_MAXC, c->tune.slice_rows)) * half;   // rows of every round's lnprob batch
+    const int B = std::max(2, std::min(8, c->tune.slice_rows)) * half;   // rows of every round's lnprob batch
     const int per = (B + G - 1) / G;
     // device state (doubles first): pos (W,D) | lp (W) | trial (B,D) | lnp_rows (B) | X0, eta (half,D each) |
     // Z0, L, R (half each) | T (half, MAXC) | mu[3] | mu_hist (nsteps) | block results (per) | chain chunk; then the integer state

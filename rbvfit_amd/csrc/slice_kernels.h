@@ -31,7 +31,10 @@ namespace vp {
 constexpr int SL_OUT = 0, SL_SHRINK = 2, SL_DONE = 3;
 constexpr int SLICE_MAX_HALF = 2048;    // one workgroup of <= 1024 threads handles a half-ensemble, up to SLICE_KPT walkers per thread (W <= 4096)
 constexpr int SLICE_KPT = 2;
-constexpr int SLICE_MAXC = 8;           // candidates a walker may have in one round
+#ifndef VP_SLICE_MAXC
+#define VP_SLICE_MAXC 8
+#endif
+constexpr int SLICE_MAXC = VP_SLICE_MAXC;   // candidates a walker may have in one round
 
 struct SliceState {          // per walker-slot k of the active half (device arrays of length half)
     double* X0;              // (half, D) position at the start of the half-step
