@@ -496,7 +496,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             waves += (long)Wp * in.dev_w.ntiles;
         }
         // (measured on C3, two instruments of 8192 pixels = 52 single-wave tiles per walker, us per pass, launches / one launch:
-        //  64 walkers 67.5 / 56.7, 256: 89.2 / 92.5, 512: 143.1 / 143.9, 1024: 229 / 251, 2048: 401 / 468 -- the long LSF's tiles carry
+        //  64 walkers 67.5 / 47.6, 256: 89.2 / 92.5, 512: 143.1 / 143.9, 1024: 229 / 251, 2048: 401 / 468 -- the long LSF's tiles carry
         //  more halo as single waves, which only a batch that leaves the GPU mostly idle does not feel)
         if (multi && c->tune.tile_multi < 0 && waves > 6144) multi = false;
         if (multi) {
@@ -515,7 +515,9 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             }
             for (size_t k = ni; k < 4; ++k) { tb.t[k - 1] = tsum; tb.off[k] = tsum; }
             const int nt = c->total_tiles_w;
-            int fm = ((long)Wp * nt < 6144) ? 1 : 0;
+            // (final reduction by its own launch: with these many single-wave tiles per walker the ticket's round trips at the
+            //  end of every wave cost more -- C3 at 64 walkers 56.9 us by ticket, 47.6 by launch; scripts/structure_check.py)
+            int fm = 0;
             if (c->tune.finalize >= 0) fm = c->tune.finalize ? 1 : 0;
             const vp::FinalizeArgs fw{c->d_ticket, c->d_tile_off + 2 * (ni + 1), c->d_sum_logw, d_out, (int)ni, nt, fm};
             const dim3 grid(W, nt), block(64);

@@ -1,0 +1,82 @@
+"""GPU box: is the launch structure `enqueue_lnprob` picks for a batch the fastest one this box offers?
+
+For a list of (config, walkers) the device-resident lnprob pass is timed (HIP events around back-to-back passes, median of
+several blocks) with the automatic choice and with every alternative forced through the per-context options: the one-launch
+walker kernel on / off, one-pass / two-pass tiles, final reduction by ticket / by launch, far-field expansions on / off, tiles
+of several instruments in one launch on / off.  Prints a table and the ratio auto / best; `tests/test_gpu_structure.py` runs
+the same function and asserts the ratio stays below its tolerance.  The crossovers are coded in csrc/capi.hip with the
+measurements they came from; this is the check that they still hold on the box the library runs on."""
+import itertools
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+ALTERNATIVES = {          # option -> values to force (the automatic value is -1 for each)
+    "walker": (0, 1), "geom": (0, 1), "finalize": (0, 1), "farfield": (0, 1), "tile_multi": (0, 1),
+}
+
+
+def time_pass(eng, d_theta, d_out, W, stream, npass=60, blocks=5):
+    import torch
+    ts = []
+    for _ in range(blocks):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(npass):
+            eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / npass)
+    return float(np.median(ts))
+
+
+def check(config, W, pixels=None, options=("walker", "geom", "finalize", "tile_multi"), npass=60):
+    """{'auto': (ms, kind), 'alternatives': {(opt, val): (ms, kind)}, 'ratio': auto / best}.  Options whose forced value
+    cannot apply to the batch (the walker kernel on a 16384-pixel spectrum) simply time the structure that runs instead."""
+    import torch
+    from rbvfit_amd.workloads import make_workload
+    wl = make_workload(config, walkers=W, pixels=pixels)
+    eng = wl.engine
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    d_theta = torch.from_numpy(wl.thetas).cuda()
+    d_out = torch.empty(W, dtype=torch.float64, device="cuda")
+    ref = None
+    out = {"alternatives": {}}
+    try:
+        for _ in range(100):
+            eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
+        torch.cuda.synchronize()
+        out["auto"] = (time_pass(eng, d_theta, d_out, W, stream, npass), eng.last_launch_kind)
+        ref = d_out.cpu().numpy().copy()
+        for opt in options:
+            for val in ALTERNATIVES[opt]:
+                eng.set_option(opt, val)
+                for _ in range(20):
+                    eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
+                torch.cuda.synchronize()
+                ms = time_pass(eng, d_theta, d_out, W, stream, npass)
+                got = d_out.cpu().numpy()
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isfinite(got), fin) and np.allclose(got[fin], ref[fin], rtol=1e-12, atol=0), (opt, val)
+                out["alternatives"][(opt, val)] = (ms, eng.last_launch_kind)
+                eng.set_option(opt, -1)
+    finally:
+        eng.close()
+    best = min([out["auto"][0]] + [v[0] for v in out["alternatives"].values()])
+    out["ratio"] = out["auto"][0] / best
+    return out
+
+
+CASES = [("C1", 64, None), ("C1", 256, None), ("C1", 512, None), ("C1", 1024, None), ("C1", 4096, None),
+         ("C2", 256, None), ("C2", 1024, None), ("C3", 64, None), ("C3", 256, None), ("C3", 2048, None), ("C4", 64, None), ("C4", 512, None)]
+
+if __name__ == "__main__":
+    for cfg, W, px in CASES:
+        opts = ("walker", "geom", "finalize", "farfield", "tile_multi") if cfg != "C1" else ("walker", "geom", "finalize")
+        r = check(cfg, W, px, opts, npass=40 if cfg in ("C1",) else 12)
+        alts = "  ".join(f"{o}={v}: {1e3 * ms:.1f} ({k})" for (o, v), (ms, k) in r["alternatives"].items())
+        print(f"{cfg} W={W:5d}: auto {1e3 * r['auto'][0]:8.1f} us ({r['auto'][1]}), auto / best = {r['ratio']:.3f}   | {alts}", flush=True)
