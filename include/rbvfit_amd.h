@@ -141,9 +141,13 @@ int vp_stretch_run(vp_ctx* ctx, int W, int D, double* pos, double* lnprob, int h
  * ensemble slice sampling with the differential move.  Per iteration the ensemble is split at random in two
  * halves; every walker of the active half slices along mu * 2.38/sqrt(2 D) * (X_l - X_m) (l != m from the other
  * half) with stepping-out and shrinking.  The ragged sets of still-active walkers are compacted ON the GPU: each
- * round is one lnprob batch of slice_rows * W/2 rows ("slice_rows" option, 2 ... 8, default 2: W rows -- the next 2 ... 8
- * trial points of every active walker first, the rest prior-rejected filler), and the host only reads one word per
- * group of rounds to learn whether the half-step is finished.
+ * round is one lnprob batch of slice_rows * W/2 rows ("slice_rows" option, 2 ... 8, default 2: W rows; at most 4096 --
+ * the next 2 ... 8 trial points of every active walker first, the rest prior-rejected filler).  The loop itself runs
+ * on the GPU as well: one single-workgroup kernel between two batches consumes the results and decides what the next
+ * batch is (more candidates, the other half-ensemble, the next iteration with its chain row and mu tuning, or nothing
+ * more), so the host only enqueues (batch, round kernel) pairs, a few ahead of the device, and synchronises once per
+ * segment of iterations (the whole call unless the chain is larger than 256 MB).  While the call runs the calling
+ * thread polls a word of mapped host memory.
  *   pos, lnprob, have_lnprob, seed, step0, chain, chain_lnprob: as in vp_stretch_run.  W even, 4 <= W <= 4096.
  *   mu         in: initial scale (zeus: 1.0), out: scale after the run.
  *   tune       != 0: adapt mu after every iteration (mu *= 2 n_expansions / (n_expansions + n_contractions)),

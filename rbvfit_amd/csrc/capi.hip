@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1262,27 +1263,31 @@ static int slice_run_impl(vp_multi* m, vp_ctx* const* cx, int G, int W, int D, d
         SFAIL(0, VP_EINVAL, "vp_slice_run: nsteps >= 0, mu > 0, maxsteps >= 1, patience >= 1, tolerance >= 0 and non-NULL mu/tune required");
     if ((chain == nullptr) != (chain_lnprob == nullptr)) SFAIL(0, VP_EINVAL, "vp_slice_run: chain and chain_lnprob go together");
     const int half = W / 2;
-    const int B = std::max(2, std::min(8, c->tune.slice_rows)) * half;   // rows of every round's lnprob batch
+    // rows of every round's lnprob batch (the round kernel keeps one slice parameter per row in LDS: <= 4096 rows)
+    const int B = std::min(2 * vp::SLICE_MAX_HALF, std::max(2, std::min(8, c->tune.slice_rows)) * half);
     const int per = (B + G - 1) / G;
-    // device state (doubles first): pos (W,D) | lp (W) | trial (B,D) | lnp_rows (B) | X0, eta (half,D each) |
-    // Z0, L, R (half each) | T (half, MAXC) | mu[3] | mu_hist (nsteps) | block results (per) | chain chunk; then the integer state
+    // A segment = the iterations the device works through on its own (slice_round_kernel) before the host collects the
+    // chain: bounded by the chain chunk (256 MB) and by the table of random splits (64 MB).
     const size_t row = (size_t)W * (D + 1);
-    size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
-    const size_t nd = (size_t)W * D + W + (size_t)B * D + 2 * (size_t)B + 2 * (size_t)half * D + (3 + vp::SLICE_MAXC) * (size_t)half + 4 +
+    size_t seg = std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)64 << 20) / ((size_t)W * sizeof(int)));
+    if (chain) seg = std::min(seg, std::max<size_t>(1, ((size_t)256 << 20) / (row * sizeof(double))));
+    // device state (doubles first): pos (W,D) | lp (W) | trial (2,B,D: the rounds alternate) | lnp_rows (2B) | X0, eta (half,D each) |
+    // Z0, L, R (half each) | T (half, MAXC) | mu[4] | mu_hist (nsteps) | block results (per) | chain segment; then the integer state
+    const size_t nd = (size_t)W * D + W + 2 * (size_t)B * D + 2 * (size_t)B + 2 * (size_t)half * D + (3 + vp::SLICE_MAXC) * (size_t)half + 4 +
                       (size_t)std::max(nsteps, 1) + (size_t)per;                // (lnp_rows twice: rounds alternate between the two when G > 1)
-    const size_t ni = (size_t)W + 7 * (size_t)half + 16;                       // perm | J K phase sides nshr row widx | n_active, nan, ncand
-    struct Dev { double *pos, *lp, *trial, *rows, *mu, *muhist, *blk, *chain; long long* ll; int *perm, *nact, *nan; vp::SliceState st; vp::SliceCounters cn; hipStream_t s; };
+    const size_t ni = 7 * (size_t)half + 32 + seg * (size_t)W;                 // J K phase sides nshr row widx | counters, prog | perm table
+    struct Dev { double *pos, *lp, *trial, *rows, *mu, *muhist, *blk, *chain; long long* ll; int *perm, *nact, *nan, *prog; vp::SliceState st; vp::SliceCounters cn; hipStream_t s; };
     std::vector<Dev> dv(G);
     const double h_mu[4] = {*mu, *tune > 0 ? (double)(*tune - 1) : 0.0, *tune ? 1.0 : 0.0, 0.0};   // `tune` carries the state across calls
     for (int i = 0; i < G; ++i) {
         vp_ctx* ci = cx[i];
         STRY(i, hipSetDevice(ci->device));
         if ((rc = ensure_workspace(ci, std::max(W, B)))) { *bad = i; return rc; }
-        const size_t bytes = (nd + (i == 0 ? chunk * row : 0)) * sizeof(double) + 4 * sizeof(long long) + ni * sizeof(int) + 64;
+        const size_t bytes = (nd + (i == 0 && chain ? seg * row : 0)) * sizeof(double) + 4 * sizeof(long long) + ni * sizeof(int) + 64;
         if ((rc = ensure_scratch(ci, bytes))) { *bad = i; return rc; }
         Dev& d = dv[i];
         d.s = ci->stream;
-        d.pos = ci->d_scratch; d.lp = d.pos + (size_t)W * D; d.trial = d.lp + W; d.rows = d.trial + (size_t)B * D;
+        d.pos = ci->d_scratch; d.lp = d.pos + (size_t)W * D; d.trial = d.lp + W; d.rows = d.trial + 2 * (size_t)B * D;
         d.st = vp::SliceState{};
         d.st.X0 = d.rows + 2 * (size_t)B; d.st.eta = d.st.X0 + (size_t)half * D; d.st.Z0 = d.st.eta + (size_t)half * D;
         d.st.L = d.st.Z0 + half; d.st.R = d.st.L + half; d.st.T = d.st.R + half;
@@ -1290,18 +1295,19 @@ static int slice_run_impl(vp_multi* m, vp_ctx* const* cx, int G, int W, int D, d
         d.muhist = d.mu + 4;
         d.blk = d.muhist + std::max(nsteps, 1);
         d.chain = d.blk + per;
-        d.ll = reinterpret_cast<long long*>(d.chain + (i == 0 ? chunk * row : 0));     // n_evals, nexp, ncon, (pad)
+        d.ll = reinterpret_cast<long long*>(d.chain + (i == 0 && chain ? seg * row : 0));     // n_evals, nexp, ncon, (pad)
         int* d_int = reinterpret_cast<int*>(d.ll + 4);
-        d.perm = d_int;
-        d.st.J = d.perm + W; d.st.K = d.st.J + half; d.st.phase = d.st.K + half; d.st.sides = d.st.phase + half; d.st.nshr = d.st.sides + half;
+        d.st.J = d_int; d.st.K = d.st.J + half; d.st.phase = d.st.K + half; d.st.sides = d.st.phase + half; d.st.nshr = d.st.sides + half;
         d.st.row = d.st.nshr + half; d.st.widx = d.st.row + half;
-        d.nact = d.st.widx + half;
+        d.nact = d.st.widx + half;                                            // n_active, nanflag, ncand, (pad)
         d.nan = d.nact + 1;
+        d.prog = d.nact + 8;                                                  // 8 ints (slice_kernels.h SliceRun::prog)
+        d.perm = d.prog + 8;                                                  // (seg, W)
         d.cn = vp::SliceCounters{d.nact, d.ll, d.ll + 1, d.ll + 2, d.nan, d.nact + 2, d.mu};
         STRY(i, hipMemcpyAsync(d.pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, d.s));
         STRY(i, hipMemcpyAsync(d.mu, h_mu, sizeof(h_mu), hipMemcpyHostToDevice, d.s));
         STRY(i, hipMemsetAsync(d.ll, 0, 4 * sizeof(long long), d.s));
-        STRY(i, hipMemsetAsync(d.nact, 0, 4 * sizeof(int), d.s));
+        STRY(i, hipMemsetAsync(d.nact, 0, 16 * sizeof(int), d.s));
         ci->policy_W = 0;
         if (have_lnprob) STRY(i, hipMemcpyAsync(d.lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, d.s));
         else if ((rc = enqueue_lnprob(ci, W, d.pos, d.lp, d.s))) { *bad = i; return rc; }     // (every replica: once per run)
@@ -1315,14 +1321,47 @@ static int slice_run_impl(vp_multi* m, vp_ctx* const* cx, int G, int W, int D, d
             if (!(std::fabs(h_lp[w]) <= 1.79e308))
                 SFAIL(0, VP_ENAN, "vp_slice_run: the initial lnprob of walker " + std::to_string(w) + " is not finite");
     }
+    // two words of mapped host memory that replica 0's round kernel keeps up to date: rounds consumed, done / error
+    volatile int* h_words = nullptr;
+    int* d_words = nullptr;
+    {
+        STRY(0, hipSetDevice(c->device));
+        if (!c->h_done) {
+            if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocMapped) != hipSuccess) { c->h_done = nullptr; (void)hipGetLastError(); }
+            else std::memset(c->h_done, 0, 64);
+        }
+        void* dptr = nullptr;
+        if (c->h_done && hipHostGetDevicePointer(&dptr, c->h_done, 0) == hipSuccess) {
+            h_words = reinterpret_cast<volatile int*>(c->h_done + 8);
+            d_words = reinterpret_cast<int*>(static_cast<uint32_t*>(dptr) + 8);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     int parity = 0;                                  // which of the two row-result vectors the coming round fills (G > 1)
+    int tb = 0;                                      // which of the two trial batches the coming round evaluates
     auto done_ = [&](int code) { for (int i = 0; i < G; ++i) cx[i]->policy_W = 0; return code; };
     if (G > 1 && (rc = multi_barrier(m))) return done_(rc);
-    const double gamma0 = 2.38 / std::sqrt(2.0 * (double)D);
-    const int thr = std::min(1024, ((half + 63) / 64) * 64);        // (beyond 1024 walkers per half a thread looks after two)
-    int group = 6;                                   // rounds enqueued before the host looks at n_active (adapts to the run)
-    // one round: the lnprob of the B trial rows (sharded when G > 1), then the update kernel on every replica
-    auto round = [&](int h, uint64_t step) -> int {
+    vp::SliceRun P{};
+    P.W = W; P.half = half; P.D = D; P.batch_rows = B; P.maxsteps = maxsteps; P.patience = patience;
+    P.round_limit = (int)std::min<long long>(4ll * maxsteps + 4096, 1ll << 30);
+    P.gamma0 = 2.38 / std::sqrt(2.0 * (double)D);
+    P.tolerance = tolerance; P.seed = seed;
+    auto launch_round = [&](int i, int start) {
+        const Dev& d = dv[i];
+        vp::SliceRun Pi = P;
+        // (start: the first batch goes into buffer tb; a round consumes buffer tb ^ 1 -- flipped by then -- and fills tb)
+        Pi.pos = d.pos; Pi.lp = d.lp; Pi.perm_tab = d.perm; Pi.prog = d.prog;
+        Pi.trial = d.trial + (size_t)tb * B * D;
+        Pi.trial_in = d.trial + (size_t)(tb ^ 1) * B * D;
+        Pi.host = i == 0 ? d_words : nullptr;
+        Pi.chain = i == 0 && chain ? d.chain : nullptr;
+        Pi.chain_lp = i == 0 && chain ? d.chain + seg * (size_t)W * D : nullptr;
+        Pi.mu_hist = d.muhist + (P.step_base - step0);
+        hipLaunchKernelGGL(vp::slice_round_kernel, dim3(1), dim3(1024), 0, d.s, Pi, d.st, d.cn, d.rows + (G > 1 ? (size_t)(parity ^ 1) * B : 0), start);
+    };
+    // one round: the lnprob of the B trial rows (sharded when G > 1), then the round kernel on every replica
+    auto round = [&]() -> int {
         const size_t roff = G > 1 ? (size_t)parity * B : 0;
         vp::Replicas R{};
         R.n = G;
@@ -1332,84 +1371,92 @@ static int slice_run_impl(vp_multi* m, vp_ctx* const* cx, int G, int W, int D, d
             const Dev& d = dv[i];
             STRY(i, hipSetDevice(ci->device));
             if (G == 1) {
-                if ((rc = enqueue_lnprob(ci, B, d.trial, d.rows, d.s))) { *bad = i; return rc; }
+                if ((rc = enqueue_lnprob(ci, B, d.trial + (size_t)tb * B * D, d.rows, d.s))) { *bad = i; return rc; }
             } else {
                 const int lo = std::min(i * per, B), n = std::min(lo + per, B) - lo;
                 if (n <= 0) continue;
                 ci->policy_W = B;
-                if ((rc = enqueue_lnprob(ci, n, d.trial + (size_t)lo * D, d.blk, d.s))) { *bad = i; return rc; }
+                if ((rc = enqueue_lnprob(ci, n, d.trial + ((size_t)tb * B + lo) * D, d.blk, d.s))) { *bad = i; return rc; }
                 hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, d.s, d.blk, n, lo, R);
             }
         }
         // every block's results are in every replica before any replica consumes them.  (The other hazard -- a block of
-        // the NEXT round landing in a vector a replica's update is still reading -- cannot occur: the rounds alternate
-        // between two vectors, and a replica's update of round r precedes, on its own stream, the event it records in
+        // the NEXT round landing in a vector a replica's round kernel is still reading -- cannot occur: the rounds alternate
+        // between two vectors, and a replica's kernel of round r precedes, on its own stream, the event it records in
         // round r + 1, which every scatter of round r + 2 waits for.)
         if (G > 1 && (rc = multi_barrier(m))) return rc;
-        for (int i = 0; i < G; ++i) {
-            const Dev& d = dv[i];
-            STRY(i, hipSetDevice(cx[i]->device));
-            hipLaunchKernelGGL(vp::slice_update_kernel, dim3(1), dim3(thr), 0, d.s, d.pos, d.lp, d.rows + roff, half, D, h, seed,
-                               step, B, d.st, d.cn, d.trial);
-        }
         parity ^= 1;
+        tb ^= 1;
+        for (int i = 0; i < G; ++i) {
+            STRY(i, hipSetDevice(cx[i]->device));
+            launch_round(i, 0);
+        }
         return VP_OK;
     };
+    const int ahead = 8;                             // rounds the host keeps enqueued beyond the last one it has seen consumed
     for (int done = 0; done < nsteps;) {
-        const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
-        for (int it = 0; it < n; ++it) {
-            const uint64_t step = step0 + (uint64_t)(done + it);
-            // mu tuning from the PREVIOUS iteration of this call, then this iteration's random split
-            for (int i = 0; i < G; ++i) {
-                const Dev& d = dv[i];
-                STRY(i, hipSetDevice(cx[i]->device));
-                hipLaunchKernelGGL(vp::slice_begin_kernel, dim3(1), dim3(1024), 0, d.s, W, seed, step, d.perm, d.cn, (done + it) > 0 ? 1 : 0,
-                                   tolerance, patience, (done + it) > 0 ? d.muhist + (done + it - 1) : (double*)nullptr);
-            }
-            for (int h = 0; h < 2; ++h) {
-                for (int i = 0; i < G; ++i) {
-                    const Dev& d = dv[i];
-                    STRY(i, hipSetDevice(cx[i]->device));
-                    hipLaunchKernelGGL(vp::slice_init_kernel, dim3(1), dim3(thr), 0, d.s, d.pos, d.lp, d.perm, half, D, h, seed, step,
-                                       gamma0, maxsteps, B, d.st, d.cn, d.trial);
+        const int n = (int)std::min<size_t>(seg, (size_t)(nsteps - done));
+        P.n = n;
+        P.step_base = step0 + (uint64_t)done;
+        if (h_words) { h_words[0] = 0; h_words[1] = 0; }
+        for (int i = 0; i < G; ++i) {
+            STRY(i, hipSetDevice(cx[i]->device));
+            hipLaunchKernelGGL(vp::slice_perm_kernel, dim3(n), dim3(1024), 0, dv[i].s, W, seed, P.step_base, dv[i].perm);
+            launch_round(i, 1);
+        }
+        int enq = 0, h_prog[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto t_seen = std::chrono::steady_clock::now();
+        int last_seen = -1, idle = 0;
+        for (;;) {
+            if (h_words) {
+                if (__atomic_load_n(const_cast<int*>(h_words + 1), __ATOMIC_ACQUIRE)) break;
+                const int seen = __atomic_load_n(const_cast<int*>(h_words), __ATOMIC_RELAXED);
+                if (enq - seen >= ahead) {           // far enough ahead: wait for the device (and notice a stream that died)
+                    __builtin_ia32_pause();
+                    if (seen != last_seen) { last_seen = seen; t_seen = std::chrono::steady_clock::now(); idle = 0; }
+                    else if (++idle > 20000) { std::this_thread::sleep_for(std::chrono::microseconds(20)); }   // (rounds of milliseconds: big models)
+                    else if (std::chrono::steady_clock::now() - t_seen > std::chrono::seconds(5)) {
+                        STRY(0, hipSetDevice(c->device));
+                        const hipError_t q = hipStreamQuery(dv[0].s);
+                        if (q != hipErrorNotReady) {     // the queue ran dry (or failed) without the word moving
+                            if (q != hipSuccess) { (void)hipGetLastError(); *bad = 0; return done_(fail(c, VP_EHIP, std::string("vp_slice_run: ") + hipGetErrorString(q))); }
+                            if (!__atomic_load_n(const_cast<int*>(h_words + 1), __ATOMIC_ACQUIRE) &&
+                                __atomic_load_n(const_cast<int*>(h_words), __ATOMIC_RELAXED) == seen) h_words = nullptr;   // word not delivered: poll by copy
+                        }
+                        t_seen = std::chrono::steady_clock::now();
+                    }
+                    continue;
                 }
-                int rounds = 0;
-                for (;;) {
-                    for (int r = 0; r < group; ++r)
-                        if ((rc = round(h, step))) return done_(rc);
-                    rounds += group;
-                    int h_state[2] = {0, 0};
-                    STRY(0, hipSetDevice(c->device));
-                    STRY(0, hipMemcpyAsync(h_state, dv[0].nact, 2 * sizeof(int), hipMemcpyDeviceToHost, dv[0].s));
-                    STRY(0, hipStreamSynchronize(dv[0].s));
-                    if (h_state[1]) { *bad = 0; return done_(fail(c, VP_ENAN, "vp_slice_run: Log Probability returned NaN")); }
-                    if (h_state[0] == 0) break;
-                    if (rounds > 4 * maxsteps + 4096) { *bad = 0; return done_(fail(c, VP_ESTATE, "vp_slice_run: a slice did not terminate")); }
-                    group = 2;                       // stragglers: look again after a couple of rounds
-                }
-                group = std::max(2, std::min(16, rounds));   // next half-step: about as many rounds as this one needed
-            }
-            if (chain) {
+                if ((rc = round())) return done_(rc);
+                ++enq;
+            } else {                                 // no mapped word: look at the device's state every few rounds
+                for (int r = 0; r < ahead; ++r)
+                    if ((rc = round())) return done_(rc);
                 STRY(0, hipSetDevice(c->device));
-                STRY(0, hipMemcpyAsync(dv[0].chain + (size_t)it * W * D, dv[0].pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToDevice, dv[0].s));
-                STRY(0, hipMemcpyAsync(dv[0].chain + chunk * (size_t)W * D + (size_t)it * W, dv[0].lp, (size_t)W * sizeof(double),
-                                       hipMemcpyDeviceToDevice, dv[0].s));
+                STRY(0, hipMemcpyAsync(h_prog, dv[0].prog, sizeof(h_prog), hipMemcpyDeviceToHost, dv[0].s));
+                STRY(0, hipStreamSynchronize(dv[0].s));
+                if (h_prog[2]) break;
             }
         }
+        // the segment is over on the device: drain what is still enqueued (launches that return at once), look at the outcome
+        for (int i = G - 1; i >= 0; --i) {
+            STRY(i, hipSetDevice(cx[i]->device));
+            if (i == 0) STRY(0, hipMemcpyAsync(h_prog, dv[0].prog, sizeof(h_prog), hipMemcpyDeviceToHost, dv[0].s));
+            STRY(i, hipStreamSynchronize(dv[i].s));
+        }
         STRY(0, hipGetLastError());
+        if (h_prog[3] == 1) { *bad = 0; return done_(fail(c, VP_ENAN, "vp_slice_run: Log Probability returned NaN")); }
+        if (h_prog[3]) { *bad = 0; return done_(fail(c, VP_ESTATE, "vp_slice_run: a slice did not terminate")); }
         if (chain) {
-            STRY(0, hipSetDevice(c->device));
             STRY(0, hipMemcpyAsync(chain + (size_t)done * W * D, dv[0].chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, dv[0].s));
-            STRY(0, hipMemcpyAsync(chain_lnprob + (size_t)done * W, dv[0].chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
+            STRY(0, hipMemcpyAsync(chain_lnprob + (size_t)done * W, dv[0].chain + seg * (size_t)W * D, (size_t)n * W * sizeof(double),
                                    hipMemcpyDeviceToHost, dv[0].s));
             STRY(0, hipStreamSynchronize(dv[0].s));
         }
+        if (G > 1 && (rc = multi_barrier(m))) return done_(rc);
         done += n;
     }
-    // the last iteration's tuning step (so that mu / mu_history cover every iteration of the call)
     STRY(0, hipSetDevice(c->device));
-    if (nsteps > 0)
-        hipLaunchKernelGGL(vp::slice_tune_kernel, dim3(1), dim3(1), 0, dv[0].s, dv[0].cn, tolerance, patience, dv[0].muhist + (nsteps - 1));
     double h_mu_out[4];
     long long h_ll[4];
     STRY(0, hipMemcpyAsync(pos, dv[0].pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, dv[0].s));
@@ -1449,6 +1496,12 @@ extern "C" int vp_debug_read_ff(vp_ctx* c, double* out, long n) {
     if (!c || !c->d_ff) return -1;
     hipDeviceSynchronize();
     return hipMemcpy(out, c->d_ff, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+// diagnostic build only: thread 0's clock at the phases of the slice sampler's round kernels (round, stage)
+extern "C" int vp_debug_read_slice_stamps(long long* out, int n) {
+    const size_t bytes = sizeof(long long) * (size_t)std::min(n, vp::SLICE_STAMP_ROUNDS * vp::SLICE_STAMP_STAGES);
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vp::g_slice_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 // diagnostic build only: the walker kernel's phase stamps of the last launch (shader clock), (walker, wave, stage)
 extern "C" int vp_debug_read_stamps(long long* out, int n) {
