@@ -55,6 +55,8 @@ struct Tuning {
                                 // (0: hipStreamSynchronize; measured 512-walker C1 call 42.7 -> ~33 us)
     int no_ff_members = 0;      // (read when an instrument is added) never take cluster members into the far-field expansions one by one
     int tile_multi = -1;        // tiles of several instruments in one launch (tile_kernel_multi): -1 by batch size, 0 never, 1 whenever possible
+    int tile_lpt = 1;           // (read when an instrument is added) tile launches hand out the tiles with the most line cores
+                                // first (0: in grid order)
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
 };
 
@@ -68,6 +70,7 @@ const Knob g_knobs[] = {
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
+    VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -811,12 +814,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
-    {
-        const std::vector<int> zeros(vp::WALKER_THREADS_MAX / 64, 0);
-        int* d_hint;
-        if ((rc = upload<int>(c, &in, zeros.data(), zeros.size(), &d_hint))) { for (void* p : in.allocs) hipFree(p); return rc; }
-        d.core_hint = d_hint;
-    }
+    d.core_hint = nullptr;                               // (per geometry, below)
     d.ff_tab = nullptr; d.ff = nullptr; d.ff_nblk = 0; d.ff_members = 0;
     in.dev_s = d;                                        // one-pass tiles for small batches (same LDS layout rules)
     {
@@ -922,6 +920,46 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
                     std::to_string(c->lds_limit));
     }
     in.sum_logw = neumaier_sum(log_inv_sigma2, P);
+    // Per geometry: walker_kernel's hints (zero), then the order in which tile_kernel hands out the tiles -- by estimated
+    // cost, the most expensive first, so that a launch ends on cheap workgroups wherever the lines sit on the grid: cost =
+    // the tile's pixels within +-300 km/s of a line centre (at v = 0), summed over the lines (where the line-core and
+    // near-wing tiers run); ties, and grids without lines, keep the grid order.
+    {
+        std::vector<int> core_lo(L, 1), core_hi(L, 0);
+        if (P > 1 && wave[P - 1] > wave[0] && c->tune.tile_lpt) {
+            for (int l = 0; l < L; ++l) {
+                const double wc = lambda0[l] * zfac[l], hw = wc * (300.0 / 299792.458);
+                const int lo = (int)(std::lower_bound(wave, wave + P, wc - hw) - wave);
+                const int hi = (int)(std::upper_bound(wave, wave + P, wc + hw) - wave) - 1;
+                if (hi >= lo) { core_lo[l] = lo; core_hi[l] = hi; }
+            }
+        }
+        vp::InstDev* geoms[3] = {&in.dev, &in.dev_s, &in.dev_w};
+        for (int gi = 0; gi < 3; ++gi) {
+            vp::InstDev* gd = geoms[gi];
+            bool reused = false;
+            for (int gj = 0; gj < gi && !reused; ++gj)
+                if (geoms[gj]->TP == gd->TP && geoms[gj]->ntiles == gd->ntiles) { gd->core_hint = geoms[gj]->core_hint; reused = true; }
+            if (reused) continue;
+            std::vector<int> tabl(vp::TILE_ORDER_AT + gd->ntiles, 0);
+            std::vector<long> cost(gd->ntiles, 0);
+            bool any = false;
+            for (int l = 0; l < L; ++l)
+                for (int t = core_lo[l] / gd->TP; core_hi[l] >= core_lo[l] && t <= std::min(gd->ntiles - 1, core_hi[l] / gd->TP); ++t) {
+                    cost[t] += std::min(core_hi[l], (t + 1) * gd->TP - 1) - std::max(core_lo[l], t * gd->TP) + 1;
+                    any = true;
+                }
+            if (any && gd->ntiles > 1) {
+                std::vector<int> idx(gd->ntiles);
+                for (int t = 0; t < gd->ntiles; ++t) idx[t] = t;
+                std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+                for (int t = 0; t < gd->ntiles; ++t) tabl[vp::TILE_ORDER_AT + t] = idx[t] + 1;
+            }
+            int* d_tabl;
+            if ((rc = upload<int>(c, &in, tabl.data(), tabl.size(), &d_tabl))) { for (void* p : in.allocs) hipFree(p); return rc; }
+            gd->core_hint = d_tabl;
+        }
+    }
     in.h_lambda0.assign(lambda0, lambda0 + L); in.h_gamma.assign(gamma, gamma + L); in.h_bidx.assign(b_idx, b_idx + L);
     in.h_lines.assign(lambda0, lambda0 + L); in.h_lines.insert(in.h_lines.end(), gamma, gamma + L);
     in.h_lines.insert(in.h_lines.end(), f, f + L); in.h_lines.insert(in.h_lines.end(), zfac, zfac + L);

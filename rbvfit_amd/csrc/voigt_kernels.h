@@ -86,8 +86,10 @@ struct InstDev {
                            // whose blocks are a few Doppler widths wide: C4; pointless, and a little slower, on coarse grids)
     int* core_hint;        // (16) walker_kernel: tile t met line cores in an earlier launch -> its wave stages the Dawson
                            // table while it waits for the records instead of between phase A and phase B (a hint only:
-                           // results never depend on it)
+                           // results never depend on it); behind them (TILE_ORDER_AT ...) tile_kernel's order of the
+                           // geometry's tiles: entry i = 1 + the tile handed to blockIdx.y = i, or 0 = tile i
 };
+constexpr int TILE_ORDER_AT = 16;
 
 // ---------------------------------------------------------------------------------------------
 // compile-time table of the wing-series polynomials  C_m(a^2) = sum_i WC[m][i] a^(2i)
@@ -1275,9 +1277,12 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(Ins
                                                             int out_offset, FinalizeArgs F,
                                                             const int* __restrict__ genflag) {
     extern __shared__ double fl[];
-    // walkers are the fast grid dimension and the (short) last tile comes last, so the tail of the
-    // launch is filled with the cheapest workgroups
-    const int t = blockIdx.y, w = blockIdx.x;
+    // walkers are the fast grid dimension; the tiles come in the order of the geometry's table (I.core_hint + TILE_ORDER_AT:
+    // those with the most line cores first, capi.hip) or, where it says 0, in grid order -- the (short) last tile last --,
+    // so the tail of the launch is filled with the cheapest workgroups.  (Which workgroup evaluates a tile does not enter
+    // its result.)
+    const int ot = I.core_hint[TILE_ORDER_AT + blockIdx.y];
+    const int t = ot > 0 ? ot - 1 : (int)blockIdx.y, w = blockIdx.x;
     const int oob = (OUT == 0) ? flags[w] : 0;   // tested below, after the first loads are in flight
     const int gen = genflag ? genflag[w] : 0;
     const int p0 = t * I.TP, nout = min(p0 + I.TP, I.P) - p0;
