@@ -564,8 +564,9 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             vp::InstDev g2 = geom;
             g2.ff = ff;
             const int nbk = geom.ntiles * geom.ff_nblk;
-            if (g2.ff_members) hipLaunchKernelGGL((vp::farfield_kernel<9, true>), dim3((nbk + 63) / 64, W), dim3(64), 0, s, g2, in.lines, c->d_lc, W);
-            else hipLaunchKernelGGL((vp::farfield_kernel<6, false>), dim3((nbk + 63) / 64, W), dim3(64), 0, s, g2, in.lines, c->d_lc, W);
+            const size_t ffl = vp::farfield_lds_bytes(in.lines.L, in.lines.NCm);
+            if (g2.ff_members) hipLaunchKernelGGL((vp::farfield_kernel<9, true>), dim3((nbk + 63) / 64, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, in.lines, c->d_lc, W);
+            else hipLaunchKernelGGL((vp::farfield_kernel<6, false>), dim3((nbk + 63) / 64, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, in.lines, c->d_lc, W);
         }
         size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin,

@@ -477,19 +477,56 @@ __device__ __forceinline__ void ff_cluster_accum(const double (&pq)[FF_KMAX], do
     }
 }
 
+// What farfield_kernel reads of a walker's records, staged in LDS by one round of vector loads (the records are 512 B
+// apart and were read field by field with scalar loads: a memory round trip per item, in a launch that is a chain of them):
+// per line K_0..K_8 | A | B | mode (FF_LF doubles), per cluster Q_2..Q_16 | A_c | B_c | Y_0..Y_4 | first, count (FF_CF).
+// The workgroup can be FF_WAVES waves over the SAME 64 blocks: wave h takes the items (clusters, then lines) h, h + FF_WAVES,
+// ..., and wave 0 adds the others' coefficients to its own, in wave order, through LDS.  Measured with 2: C2 -1 %, C3 -2 %,
+// C4 +3 % per pass (profiles/r03_notes.md) -- the launch is bound by its instruction count (~150 per item and wave), not
+// by the length of a wave's chain -- so it stays at 1.
+constexpr int FF_LF = 12, FF_CF = 23, FF_WAVES = 1;
+__host__ __device__ inline size_t farfield_lds_bytes(int L, int NCm) {
+    return ((size_t)L * FF_LF + (size_t)NCm * FF_CF + (size_t)(FF_WAVES - 1) * 64 * (FF_NC + 2)) * sizeof(double);
+}
+
 template <int M, bool MEMBERS>      // MEMBERS: cluster members may be taken line by line (InstDev::ff_members); the plain instance is free of it
-__global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, const double* __restrict__ lc, int W) {
+__global__ __launch_bounds__(64 * FF_WAVES) void farfield_kernel(InstDev I, LinesDev T, const double* __restrict__ lc, int W) {
     constexpr double XMIN = M >= 9 ? 14.0 : 30.0;
-    // one wave = 64 blocks of ONE walker (grid.y): the walker's records, the cluster tables and all the bookkeeping on
-    // them are wave-uniform (scalar loads, scalar ALU); per lane only the block's own numbers
+    extern __shared__ double ffs[];
+    // one workgroup = 64 blocks of ONE walker (grid.y), lane = block: the walker's records, the cluster tables and all
+    // the bookkeeping on them are wave-uniform; per lane only the block's own numbers
     const int nb = I.ntiles * I.ff_nblk;
     const int w = blockIdx.y;
-    const int b = min((int)(blockIdx.x * 64 + threadIdx.x), nb - 1);
-    const bool store = (int)(blockIdx.x * 64 + threadIdx.x) < nb;     // (lanes past the end repeat the last block)
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = min((int)(blockIdx.x * 64 + lane), nb - 1);
+    const bool store = (int)(blockIdx.x * 64 + lane) < nb;     // (lanes past the end repeat the last block)
     const long idx = (long)w * nb + b;
     double* __restrict__ out = I.ff + (size_t)idx * FF_STRIDE;
     const double gc = I.ff_tab[4 * b], hw = I.ff_tab[4 * b + 1];
-    rec_t recs = as_rec(lc + (size_t)w * (T.L + T.NCm) * LC_STRIDE);      // (written by the launch before: scalar loads)
+    const double* __restrict__ recs = lc + (size_t)w * (T.L + T.NCm) * LC_STRIDE;      // (written by the launch before)
+    double* __restrict__ sl = ffs;                               // (L, FF_LF)
+    double* __restrict__ sq = ffs + (size_t)T.L * FF_LF;         // (NCm, FF_CF)
+    {
+        const int nl = T.L * FF_LF, nq = T.NCm * FF_CF;
+        for (int e = threadIdx.x; e < nl + nq; e += 64 * FF_WAVES) {
+            double v;
+            if (e < nl) {
+                const int l = e / FF_LF, f = e - l * FF_LF;
+                const int off = f < 9 ? LC_K0 + f : (f == 9 ? LC_A : (f == 10 ? LC_B : LC_MODE));
+                v = recs[(size_t)l * LC_STRIDE + off];           // (mode: the raw 8 bytes)
+            } else {
+                const int k = (e - nl) / FF_CF, f = (e - nl) - k * FF_CF;
+                if (f < 22) {
+                    const int off = f < FF_KMAX ? MP_Q0 + f : (f == 15 ? MP_A : (f == 16 ? MP_B : MP_Y0 + (f - 17)));
+                    v = recs[(size_t)(T.L + k) * LC_STRIDE + off];
+                } else {
+                    v = __hiloint2double(T.cl_count[k], T.cl_first[k]);
+                }
+            }
+            ffs[e] = v;
+        }
+        __syncthreads();
+    }
     double c[FF_NC];
 #pragma unroll
     for (int j = 0; j < FF_NC; ++j) c[j] = 0.0;
@@ -504,27 +541,25 @@ __global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, con
     //      member lines are then covered together (and never one by one: the cluster's own expansion in the tile
     //      kernel must not count a line twice)
     for (int k = 0; k < T.NCm; ++k) {
-        const int first = T.cl_first[k], n = T.cl_count[k];
+        const double* __restrict__ mq = sq + (size_t)k * FF_CF;
+        const int first = __builtin_amdgcn_readfirstlane(__double2loint(mq[22])), n = __builtin_amdgcn_readfirstlane(__double2hiint(mq[22]));
         unsigned long long rm[2] = {0ull, 0ull};                 // the members' bits (wave-uniform)
         for (int l = first; l < first + n; ++l) rm[l >> 6] |= 1ull << (l & 63);
         member[0] |= rm[0]; member[1] |= rm[1];
-        rec_t mrec = recs + (size_t)(T.L + k) * LC_STRIDE;
-        // everything the item may need in ONE batch of scalar loads (its address does not wait for the tables above):
-        // the launch is a chain of load round trips, one per item this way instead of three
         double Qk[FF_KMAX];
 #pragma unroll
-        for (int jq = 0; jq < FF_KMAX; ++jq) Qk[jq] = mrec[MP_Q0 + jq];
-        const double Ac = mrec[MP_A], Bc = mrec[MP_B];
+        for (int jq = 0; jq < FF_KMAX; ++jq) Qk[jq] = mq[jq];
+        const double Ac = mq[15], Bc = mq[16], Y0c = mq[17];
         const double yc = __builtin_fma(Ac, gc, -Bc), ayc = fabs(yc), hwy = fabs(Ac) * hw, ynear = ayc - hwy;
-        int J = ynear >= mrec[MP_Y0 + 4] ? MP_J4 : (ynear >= mrec[MP_Y0 + 3] ? MP_J3 : (ynear >= mrec[MP_Y0 + 2] ? MP_J2 :
-                (ynear >= mrec[MP_Y0 + 1] ? MP_J1 : 0)));
+        int J = ynear >= mq[21] ? MP_J4 : (ynear >= mq[20] ? MP_J3 : (ynear >= mq[19] ? MP_J2 : (ynear >= mq[18] ? MP_J1 : 0)));
         {
             // (the tile kernel uses the multipole of a pass only if EVERY pixel has |y| >= Y_0: with the block's farthest
             //  pixel inside that radius -- a hair inside, for the roundings of y -- it cannot, whatever the pass looks like)
-            const bool inside = MEMBERS && live && (ayc + hwy) * (1.0 + 1e-9) < mrec[MP_Y0];
+            const bool inside = MEMBERS && live && (ayc + hwy) * (1.0 + 1e-9) < Y0c;
             if (inside) { solo[0] |= rm[0]; solo[1] |= rm[1]; }
             if (__ballot(inside) != 0ull) { visit[0] |= rm[0]; visit[1] |= rm[1]; }
         }
+        if (k % FF_WAVES != half) continue;                     // (the bookkeeping above: every wave; the expansion: one)
         bool ok = live && J > 0 && hwy <= 0.125 * ayc;
         const double iyc = fast_rcp(yc);
         if (ok) {
@@ -550,13 +585,14 @@ __global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, con
     for (int l = 0; l < T.L; ++l) {
         const bool is_member = (member[l >> 6] >> (l & 63)) & 1ull;
         if (is_member && !(MEMBERS && ((visit[l >> 6] >> (l & 63)) & 1ull))) continue;
+        if ((T.NCm + l) % FF_WAVES != half) continue;
         const bool mine = !MEMBERS || !is_member || ((solo[l >> 6] >> (l & 63)) & 1ull);     // (per lane)
-        rec_t rec = recs + (size_t)l * LC_STRIDE;
+        const double* __restrict__ rl = sl + (size_t)l * FF_LF;
         double Kl[M];
 #pragma unroll
-        for (int mm = 0; mm < M; ++mm) Kl[mm] = rec[LC_K0 + mm];
-        const double A = rec[LC_A], B = rec[LC_B], K0 = Kl[0];
-        const int mode = rec_int(rec, LC_MODE, 0);
+        for (int mm = 0; mm < M; ++mm) Kl[mm] = rl[mm];
+        const double A = rl[9], B = rl[10], K0 = Kl[0];
+        const int mode = __double2loint(rl[11]);
         const double xc = __builtin_fma(A, gc, -B), axc = fabs(xc), hwx = fabs(A) * hw;
         bool ok = live && mine && mode == 0 && (axc - hwx >= XMIN) && (hwx <= 0.125 * axc);
         const double ixc = fast_rcp(xc), sc = ixc * ixc;
@@ -584,6 +620,26 @@ __global__ __launch_bounds__(64) void farfield_kernel(InstDev I, LinesDev T, con
             rj *= r;
         }
         if (ok) mask[l >> 6] |= 1ull << (l & 63);
+    }
+    if (FF_WAVES > 1) {
+        double* __restrict__ xs = ffs + (size_t)T.L * FF_LF + (size_t)T.NCm * FF_CF;      // (FF_WAVES - 1, FF_NC + 2, 64)
+        if (half > 0) {
+            double* __restrict__ mine = xs + (size_t)(half - 1) * (FF_NC + 2) * 64;
+#pragma unroll
+            for (int j = 0; j < FF_NC; ++j) mine[j * 64 + lane] = c[j];
+            reinterpret_cast<unsigned long long*>(mine)[FF_NC * 64 + lane] = mask[0];
+            reinterpret_cast<unsigned long long*>(mine)[(FF_NC + 1) * 64 + lane] = mask[1];
+        }
+        __syncthreads();
+        if (half > 0) return;
+#pragma unroll
+        for (int h = 1; h < FF_WAVES; ++h) {
+            const double* __restrict__ oth = xs + (size_t)(h - 1) * (FF_NC + 2) * 64;
+#pragma unroll
+            for (int j = 0; j < FF_NC; ++j) c[j] += oth[j * 64 + lane];
+            mask[0] |= reinterpret_cast<const unsigned long long*>(oth)[FF_NC * 64 + lane];
+            mask[1] |= reinterpret_cast<const unsigned long long*>(oth)[(FF_NC + 1) * 64 + lane];
+        }
     }
     if (!store) return;
 #pragma unroll
