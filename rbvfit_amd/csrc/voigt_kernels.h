@@ -956,6 +956,52 @@ __device__ __forceinline__ void lsf_block(const InstDev& I, const double* __rest
     }
 }
 
+// LSF + chi^2 (or flux output) for one block of LSF_PX * nthreads output pixels starting at `ob`: each lane produces LSF_PX
+// CONSECUTIVE pixels from one sliding window of the flux held in registers -- per group of 8 taps 8 + LSF_PX - 1 doubles
+// read for 8 LSF_PX FMAs.  The phase is bound by LDS bandwidth, not by its FMAs (C2: 22 of the tile kernel's 102 us with
+// two pixels per lane, which read 10 doubles per 16 FMAs): six pixels per lane read 14 per 48, and their lane stride of
+// 48 B keeps the 16-byte reads conflict-free (8 lanes x 16 B cover the 32 banks once).  Per output the taps are
+// accumulated in ascending order, as in the plain loop.
+constexpr int LSF_PX = 6;
+template <int OUT>
+__device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __restrict__ fl, int kn, int ob, int nout, int p0, int w,
+                                           int tid, double* __restrict__ out, int out_stride, double& acc) {
+    const int o0 = ob + LSF_PX * tid;                                         // even
+    const int oc = min(o0, ((nout - 1) / LSF_PX) * LSF_PX);                   // lanes past the end repeat the last group
+    const double2* __restrict__ fw = reinterpret_cast<const double2*>(fl + oc);
+    double m[LSF_PX];
+#pragma unroll
+    for (int p = 0; p < LSF_PX; ++p) m[p] = 0.0;
+    constexpr int NW = (8 + LSF_PX - 1 + 1) / 2;                              // 16-byte reads per group of 8 taps
+    for (int j = 0; j < kn; j += 8) {
+        rec_t kb = as_rec(I.kflip) + j;                       // uniform address: scalar loads, SGPR operands of the FMAs
+        double f[2 * NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const double2 v = fw[(j >> 1) + q];
+            f[2 * q] = v.x; f[2 * q + 1] = v.y;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double kj = kb[u];
+#pragma unroll
+            for (int p = 0; p < LSF_PX; ++p) m[p] = __builtin_fma(kj, f[u + p], m[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < LSF_PX; ++p) {
+        const int px = p0 + o0 + p;
+        if (o0 + p < nout) {
+            if (OUT == 0) {
+                const double d = I.flux[px] - m[p];
+                acc = __builtin_fma(d * d, I.w[px], acc);     // (flux-model)^2 * inv_sigma2
+            } else {
+                out[(size_t)w * out_stride + px] = m[p];
+            }
+        }
+    }
+}
+
 // FF: the first line >= `from` of the 64-line word [l0, l1) whose bit in `nearm` is set (not covered by the block's
 // far-field expansion), or l1.
 __device__ __forceinline__ int next_near_line(unsigned long long nearm, int from, int l0, int l1) {
@@ -1280,11 +1326,16 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
         // blocks of 4 output pixels per lane (two pairs: ILP) while more than 2 per lane remain, then blocks of 2: the
         // tail of a 362-pixel tile is one 128-pixel block instead of a mostly masked 256-pixel one.  Same pixels per
         // lane and same order of additions as one block size throughout: results do not change.
+#ifdef VP_LSF_PAIRS
         int ob = 0;
         for (; nout - ob > 2 * TILE_THREADS; ob += 4 * TILE_THREADS)
             lsf_block<2, OUT>(I, fl, Kp, ob, nout, p0, w, tid, TILE_THREADS, out, out_stride, acc);
         for (; ob < nout; ob += 2 * TILE_THREADS)
             lsf_block<1, OUT>(I, fl, Kp, ob, nout, p0, w, tid, TILE_THREADS, out, out_stride, acc);
+#else
+        for (int ob = 0; ob < nout; ob += LSF_PX * TILE_THREADS)
+            lsf_block6<OUT>(I, fl, Kp, ob, nout, p0, w, tid, out, out_stride, acc);
+#endif
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }
