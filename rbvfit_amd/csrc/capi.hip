@@ -58,6 +58,8 @@ struct Tuning {
     int tile_lpt = 1;           // (read when an instrument is added) tile launches hand out the tiles with the most line cores
                                 // first (0: in grid order)
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
+    int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
+                                // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
 
 struct Knob { const char* name; const char* env; int is_long; size_t off; };
@@ -70,7 +72,7 @@ const Knob g_knobs[] = {
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
-    VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0),
+    VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -1310,6 +1312,7 @@ static int slice_run_impl(vp_multi* m, vp_ctx* const* cx, int G, int W, int D, d
     const size_t row = (size_t)W * (D + 1);
     size_t seg = std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)64 << 20) / ((size_t)W * sizeof(int)));
     if (chain) seg = std::min(seg, std::max<size_t>(1, ((size_t)256 << 20) / (row * sizeof(double))));
+    if (c->tune.slice_seg > 0) seg = std::min(seg, (size_t)c->tune.slice_seg);
     // device state (doubles first): pos (W,D) | lp (W) | trial (2,B,D: the rounds alternate) | lnp_rows (2B) | X0, eta (half,D each) |
     // Z0, L, R (half each) | T (half, MAXC) | mu[4] | mu_hist (nsteps) | block results (per) | chain segment; then the integer state
     const size_t nd = (size_t)W * D + W + 2 * (size_t)B * D + 2 * (size_t)B + 2 * (size_t)half * D + (3 + vp::SLICE_MAXC) * (size_t)half + 4 +

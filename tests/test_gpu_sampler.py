@@ -390,6 +390,29 @@ def test_device_slice_sampler_split_runs_carry_the_tuning_state():
     assert one.n_lnprob_evals == two.n_lnprob_evals
 
 
+def test_device_slice_sampler_segments_do_not_show_in_the_chain():
+    """The device works through a SEGMENT of iterations on its own (slice_round_kernel decides what every next batch is; the
+    host only enqueues launches and collects the chain behind the segment).  Cutting a run into segments of 5 or of 1
+    iteration ("slice_seg") must not change a bit of it -- chain, lnprob, mu history, evaluation count."""
+    wl = _workload()
+    eng, p0 = wl.engine, wl.thetas
+    ref = eng.slice_run(p0, 12, seed=21)
+    try:
+        for seg in (5, 1):
+            eng.set_option("slice_seg", seg)
+            got = eng.slice_run(p0, 12, seed=21)
+            for key in ("chain", "chain_lnprob", "pos", "lnprob", "mu_history"):
+                np.testing.assert_array_equal(got[key], ref[key], err_msg=f"{key} with segments of {seg}")
+            assert got["n_evals"] == ref["n_evals"] and got["mu"] == ref["mu"] and got["tune_state"] == ref["tune_state"]
+        # no chain kept: the same final state
+        eng.set_option("slice_seg", 4)
+        got = eng.slice_run(p0, 12, seed=21, store_chain=False)
+        np.testing.assert_array_equal(got["pos"], ref["pos"])
+        np.testing.assert_array_equal(got["lnprob"], ref["lnprob"])
+    finally:
+        eng.set_option("slice_seg", 0)
+
+
 def test_device_slice_sampler_distribution_and_vfit_switch():
     from rbvfit_amd.model import FitConfiguration, VoigtModel
     from rbvfit_amd.sampler import DeviceSliceSampler
