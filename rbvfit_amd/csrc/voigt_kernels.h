@@ -963,7 +963,7 @@ __device__ __forceinline__ void lsf_block(const InstDev& I, const double* __rest
 // 48 B keeps the 16-byte reads conflict-free (8 lanes x 16 B cover the 32 banks once).  Per output the taps are
 // accumulated in ascending order, as in the plain loop.
 constexpr int LSF_PX = 6;
-template <int OUT>
+template <int OUT, bool EARLY>    // EARLY: the observed pixels are requested ahead of the taps (walker_kernel, below)
 __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __restrict__ fl, int kn, int ob, int nout, int p0, int w,
                                            int tid, double* __restrict__ out, int out_stride, double& acc) {
     const int o0 = ob + LSF_PX * tid;                                         // even
@@ -972,6 +972,18 @@ __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __res
     double m[LSF_PX];
 #pragma unroll
     for (int p = 0; p < LSF_PX; ++p) m[p] = 0.0;
+    // the observed spectrum and its weights for this lane's pixels: in walker_kernel requested now, so that they travel
+    // while the taps are applied -- behind the loop they are a memory round trip at the very end of the wave's, and the
+    // workgroup's, life (C1 at 256 walkers 16.6 -> 16.3 us); the tile launches, whose workgroups cover for each other,
+    // lose 1 % to the registers this holds (C2 / C3) and ask behind the loop
+    double fobs[LSF_PX], wobs[LSF_PX];
+    if (OUT == 0 && EARLY) {
+#pragma unroll
+        for (int p = 0; p < LSF_PX; ++p) {
+            const int px = min(p0 + o0 + p, I.P - 1);
+            fobs[p] = I.flux[px]; wobs[p] = I.w[px];
+        }
+    }
     constexpr int NW = (8 + LSF_PX - 1 + 1) / 2;                              // 16-byte reads per group of 8 taps
     for (int j = 0; j < kn; j += 8) {
         rec_t kb = as_rec(I.kflip) + j;                       // uniform address: scalar loads, SGPR operands of the FMAs
@@ -993,8 +1005,8 @@ __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __res
         const int px = p0 + o0 + p;
         if (o0 + p < nout) {
             if (OUT == 0) {
-                const double d = I.flux[px] - m[p];
-                acc = __builtin_fma(d * d, I.w[px], acc);     // (flux-model)^2 * inv_sigma2
+                const double d = (EARLY ? fobs[p] : I.flux[px]) - m[p];
+                acc = __builtin_fma(d * d, EARLY ? wobs[p] : I.w[px], acc);     // (flux-model)^2 * inv_sigma2
             } else {
                 out[(size_t)w * out_stride + px] = m[p];
             }
@@ -1334,7 +1346,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             lsf_block<1, OUT>(I, fl, Kp, ob, nout, p0, w, tid, TILE_THREADS, out, out_stride, acc);
 #else
         for (int ob = 0; ob < nout; ob += LSF_PX * TILE_THREADS)
-            lsf_block6<OUT>(I, fl, Kp, ob, nout, p0, w, tid, out, out_stride, acc);
+            lsf_block6<OUT, SOLO>(I, fl, Kp, ob, nout, p0, w, tid, out, out_stride, acc);
 #endif
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
