@@ -368,8 +368,8 @@ size_t walker_wave_lds(const vp_ctx* c) {
     for (auto& in : c->inst) b = std::max(b, in.lds_w);
     return b;
 }
-size_t walker_lds_bytes(const vp_ctx* c) {           // tiles | tile sums, prior flag, spare
-    return (size_t)walker_tiles(c) * walker_wave_lds(c) + (walker_tiles(c) + 2) * sizeof(double);
+size_t walker_lds_bytes(const vp_ctx* c) {           // tiles | tile sums, prior flag, spare | sampler form: 4 scalars, X_k, Y (64 each)
+    return (size_t)walker_tiles(c) * walker_wave_lds(c) + (walker_tiles(c) + 2 + 4 + 128) * sizeof(double);
 }
 
 #ifndef VP_WALKER_MAX_LINES

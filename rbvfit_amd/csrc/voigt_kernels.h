@@ -1592,6 +1592,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     // form -- formed here: z ~ g(z) on [1/a, a], partner j from the complementary half, Y = X_j - (X_j - X_k) z
     // (stretch_propose's arithmetic; every wave repeats the few instructions instead of waiting for one)
     double thv;
+    double* __restrict__ stash = red + nw + 2;     // sampler form: [0] (D-1) ln z, [1] ln u, [2] lnprob of X_k, [4 + lane] X_k, [68 + lane] Y
     if (SAMPLER) {
         replicas_wait(S.rep);                    // (sharded ensemble: the complementary half as the peers left it)
         const Philox4 r = draw(S.seed, S.step, S.half, S.s0 + w, 0u);
@@ -1602,6 +1603,17 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         const int d = min(lane, A.D - 1);
         const double x = S.pos[(size_t)(S.s0 + w) * A.D + d], c = S.pos[(size_t)(S.c0 + j) * A.D + d];
         thv = c - (c - x) * z;
+        // everything the accept / reject step needs besides the proposal's lnprob, by the last wave while it would wait for
+        // the records anyway: at the end of the workgroup's life it was ~2.5 us of Philox blocks, logarithms and a memory round
+        // trip on wave 0 alone
+        if (wid == nw - 1) {
+            const double lp_old = S.lp[S.s0 + w];
+            const Philox4 r1 = draw(S.seed, S.step, S.half, S.s0 + w, 1u);
+            const double lz = (double)(A.D - 1) * log(z), lu = log(u01(r1.v[0], r1.v[1]));
+            if (lane == 0) { stash[0] = lz; stash[1] = lu; stash[2] = lp_old; }
+            stash[4 + lane] = x;
+            stash[68 + lane] = thv;
+        }
     } else {
         thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
     }
@@ -1682,22 +1694,14 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     // ---- sampler form: accept / reject by wave 0 (stretch_accept's arithmetic), the walker's chain entry --------
     {
         const int ws = S.s0 + w;
-        const Philox4 r = draw(S.seed, S.step, S.half, ws, 0u);     // the proposal again (cheaper than keeping it live)
-        const double t = (S.a - 1.0) * u01(r.v[0], r.v[1]) + 1.0;
-        const double z = t * t / S.a;
-        int j = (int)(u01(r.v[2], r.v[3]) * (double)S.nC);
-        j = j < S.nC - 1 ? j : S.nC - 1;
-        const int d = min(lane, A.D - 1);
-        const double x = S.pos[(size_t)ws * A.D + d], c = S.pos[(size_t)(S.c0 + j) * A.D + d];
-        const double y = c - (c - x) * z;
-        const double lp_old = S.lp[ws];
+        const double x = stash[4 + lane], y = stash[68 + lane];     // (behind the workgroup's barriers)
+        const double lp_old = stash[2];
         bool accept = false;
         if (lnp != lnp) {
             if (lane == 0) atomicExch(S.nanflag, 1);
         } else {
-            const Philox4 r1 = draw(S.seed, S.step, S.half, ws, 1u);
-            const double lnq = (double)(A.D - 1) * log(z) + lnp - lp_old;
-            accept = log(u01(r1.v[0], r1.v[1])) < lnq;
+            const double lnq = stash[0] + lnp - lp_old;
+            accept = stash[1] < lnq;
         }
         if (accept) {
             if (S.rep.n > 0) {
@@ -1705,10 +1709,10 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
                     if (lane < A.D) S.rep.pos[rr][(size_t)ws * A.D + lane] = y;
                     if (lane == 0) S.rep.lp[rr][ws] = lnp;
                 }
-                if (lane == 0) S.nacc[ws] += 1;
+                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(S.nacc + ws), 1ull);     // (no wait for the old count)
             } else {
                 if (lane < A.D) S.pos[(size_t)ws * A.D + lane] = y;
-                if (lane == 0) { S.lp[ws] = lnp; S.nacc[ws] += 1; }
+                if (lane == 0) { S.lp[ws] = lnp; atomicAdd(reinterpret_cast<unsigned long long*>(S.nacc + ws), 1ull); }
             }
         }
         if (S.chain_pos) {
