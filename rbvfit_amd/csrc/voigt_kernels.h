@@ -48,6 +48,10 @@ struct LinesDev {          // static per-instrument line tables (CompiledModelDa
     const int* cl_count;
     const int* cl_mp;      // per line: cluster index if the line is the FIRST of a multipole cluster, else -1
     const int* cl_end;     // per line: one past the last line of its cluster
+    // the members of all clusters in a row (prep_lines_kernel forms a cluster's record with one lane per member):
+    int M;                 // members of all clusters together
+    const int* cl_moff;    // (NCm + 1) first member of every cluster in that row
+    const int* mem_cl;     // (M) cluster of every member
 };
 
 struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of a walker)
@@ -272,12 +276,95 @@ __device__ __forceinline__ void prep_cluster(const double* __restrict__ th, cons
         rec[MP_Y0 + k] = allok ? fmax(MP_X[k] + dmax, MP_R[k] * dmax) : __builtin_inf();
 }
 
+// The same record by the lanes of one wave, one lane per MEMBER (lanes base .. base + n - 1, all in this wave): the chain of a
+// lane is one member's share (~500 instructions) instead of all n of them in a row -- the record-preparation launch is as long as
+// its cluster lanes' chains (C2: 3 members, C4: 8).  Centre, radius and validity are formed from the members' numbers in member
+// order exactly as prep_cluster does; the Q_j are the members' own sums added in member order (prep_cluster keeps ONE
+// accumulator through all members: the last bits of Q_j may differ between the two, both are the same series).
+//   sh: LDS of the wave, 64 x (MPL_STRIDE doubles); j: this lane's member number, n: members, base: lane of member 0.
+constexpr int MPL_STRIDE = 27;        // Q_2..Q_27 of a member (26) + 1: lane stride of 54 banks keeps 8-byte accesses conflict-free
+__device__ __forceinline__ void prep_cluster_lanes(const double* __restrict__ th, const LinesDev& T, int k, int j, int n, int base,
+                                                   int lane, bool valid, double* __restrict__ sh, double* __restrict__ rec) {
+    const int first = T.cl_first[k];
+    const LineScalars s = line_scalars(th, T, first + j);
+    const bool ok = (s.a >= 0.0) && (s.a <= 0.1) && (fabs(s.Tl) <= 1.79e308) && (fabs(s.Ax) <= 1.79e308)
+                    && (fabs(s.Bx) <= 1.79e308) && (s.Ax > 0.0);
+    const double g0 = s.Bx * fast_rcp(s.Ax);                     // line centre in 1/wave units
+    double* __restrict__ mine = sh + (size_t)lane * MPL_STRIDE;
+    mine[0] = s.Ax; mine[1] = g0; mine[2] = ok ? 1.0 : 0.0;
+    __syncthreads();
+    bool allok = true;
+    double Ac = 1.79e308, g0sum = 0.0;
+    for (int jj = 0; jj < n; ++jj) {
+        const double* __restrict__ o = sh + (size_t)(base + jj) * MPL_STRIDE;
+        allok = allok && (o[2] != 0.0);
+        Ac = fmin(Ac, o[0]);
+        g0sum += o[1];
+    }
+    const double g0c = g0sum / (double)n;
+    const double Bc = Ac * g0c;
+    const double alpha = s.Ax * fast_rcp(Ac);                    // >= 1
+    const double delta = Ac * (g0c - g0);                        // x_l = alpha (y + delta)
+    __syncthreads();                                             // (everyone has read the first exchange)
+    // member's wing coefficients K_m, m < MP_MWING, divided by alpha^(2m+2)
+    double Km[MP_MWING];
+    const double a2 = s.a * s.a, pref = s.Tl * (s.a * INV_SQRT_PI);
+    const double ia2 = fast_rcp(alpha * alpha);
+    double ipow = ia2;
+#pragma unroll
+    for (int m = 0; m < MP_MWING; ++m) {
+        double cm = 0.0;
+#pragma unroll
+        for (int i = m; i >= 0; --i) cm = __builtin_fma(cm, a2, g_wing.c[m][i]);
+        Km[m] = pref * cm * ipow;
+        ipow *= ia2;
+    }
+    double dpow[MP_NQ + 1];                                      // (-delta)^k, k = 0..MP_NQ
+    dpow[0] = 1.0;
+#pragma unroll
+    for (int kk = 1; kk <= MP_NQ; ++kk) dpow[kk] = dpow[kk - 1] * (-delta);
+#pragma unroll
+    for (int jq = 0; jq < MP_NQ; ++jq) {
+        const int jj = jq + MP_JMIN;
+        double q = 0.0;
+#pragma unroll
+        for (int m = 0; m < MP_MWING; ++m) {
+            const int nn = 2 * m + 2;
+            if (nn <= jj) {
+                double binom = 1.0;                              // C(jj-1, nn-1), folded at compile time
+                for (int t = 1; t <= nn - 1; ++t) binom = binom * (double)(jj - 1 - (nn - 1) + t) / (double)t;
+                q = __builtin_fma(Km[m] * binom, dpow[jj - nn], q);
+            }
+        }
+        mine[jq] = q;
+    }
+    mine[MP_NQ] = fabs(delta);
+    __syncthreads();
+    if (!valid) return;
+    // the members' sums, added in member order: lane j takes Q_j, Q_(j+n), ...
+    for (int jq = j; jq < MP_NQ; jq += n) {
+        double q = 0.0;
+        for (int jj = 0; jj < n; ++jj) q += sh[(size_t)(base + jj) * MPL_STRIDE + jq];
+        rec[MP_Q0 + jq] = q;
+    }
+    if (j == 0) {
+        double dmax = 0.0;
+        for (int jj = 0; jj < n; ++jj) dmax = fmax(dmax, sh[(size_t)(base + jj) * MPL_STRIDE + MP_NQ]);
+        rec[MP_A] = Ac;
+        rec[MP_B] = Bc;
+#pragma unroll
+        for (int kk = 0; kk < MP_NTIER; ++kk)                     // inf: never use the expansion
+            rec[MP_Y0 + kk] = allok ? fmax(MP_X[kk] + dmax, MP_R[kk] * dmax) : __builtin_inf();
+    }
+}
+
 // Record preparation, one LANE per record.  Block roles by blockIdx.x:
 //   [0, nb_line)                 line records     index = blockIdx.x * rpw + lane  over (walker, line)
-//   [nb_line, nb_line + nb_cl)   cluster records  index over (walker, cluster)
+//   [nb_line, nb_line + nb_cl)   cluster records  one lane per MEMBER, cl_wpw walkers per wave (T.M <= 64 members per walker:
+//                                                 prep_cluster_lanes), or -- cl_wpw = 0 -- one lane per record over (walker, cluster)
 //   the rest                     box-prior flags  one lane per walker
 // `rpw` (records per wave, <= 64) spreads a small batch over more CUs; lanes >= rpw idle.
-struct PrepGrid { int rpw, nb_line, nb_cl, nb_flag; };
+struct PrepGrid { int rpw, nb_line, nb_cl, nb_flag, cl_wpw; };
 __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict__ theta, int W, int D,
                                                         LinesDev T, const double* __restrict__ lb,
                                                         const double* __restrict__ ub,
@@ -309,7 +396,17 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         return;
     }
     blk -= G.nb_line;
-    if (blk < G.nb_cl) {                              // ---- multipole records ----
+    if (blk < G.nb_cl && G.cl_wpw > 0) {              // ---- multipole records, a lane per member ----
+        __shared__ double sh[64 * MPL_STRIDE];
+        const int wl = lane / T.M, mi = lane - wl * T.M, w = blk * G.cl_wpw + wl;
+        const bool valid = wl < G.cl_wpw && w < W;
+        const int wv = min(w, W - 1), wlv = min(wl, G.cl_wpw - 1);                 // (idle lanes repeat a valid one's work, store nothing)
+        const int k = T.mem_cl[mi], m0 = T.cl_moff[k], n = T.cl_moff[k + 1] - m0;
+        prep_cluster_lanes(theta + (size_t)wv * D, T, k, mi - m0, n, wlv * T.M + m0, lane, valid, sh,
+                           lc + ((size_t)wv * nrec + T.L + k) * LC_STRIDE);
+        return;
+    }
+    if (blk < G.nb_cl) {                              // ---- multipole records, a lane per record ----
         const int ridx = blk * G.rpw + lane;
         if (lane >= G.rpw || ridx >= W * T.NCm) return;
         const int w = ridx / T.NCm, k = ridx - w * T.NCm;
