@@ -345,7 +345,7 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
         g.cl_wpw = 64 / in.lines.M;
         g.nb_cl = (W + g.cl_wpw - 1) / g.cl_wpw;
     }
-    g.nb_flag = do_flags ? (W + 63) / 64 : 0;
+    g.nb_flag = do_flags ? W : 0;
     hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(g.nb_line + g.nb_cl + g.nb_flag), dim3(64), 0, s, d_theta, W, c->D,
                        in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g);
 }
@@ -802,15 +802,15 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     int *d_clmp, *d_clend, *d_clfirst, *d_clcount;
     UP(int, cl_mp.data(), L, d_clmp) UP(int, cl_end.data(), L, d_clend)
     UP(int, cl_first.data(), cl_first.size(), d_clfirst) UP(int, cl_count.data(), cl_count.size(), d_clcount)
-    std::vector<int> cl_moff(1, 0), mem_cl;
+    std::vector<int4> mem_info;                      // per member of a cluster: cluster, line, first member, member count
     for (int k = 0; k < NCm; ++k) {
-        for (int j = 0; j < cl_count[k]; ++j) mem_cl.push_back(k);
-        cl_moff.push_back((int)mem_cl.size());
+        const int m0 = (int)mem_info.size();
+        for (int j = 0; j < cl_count[k]; ++j) mem_info.push_back(int4{k, cl_first[k] + j, m0, cl_count[k]});
     }
-    int *d_moff, *d_memcl;
-    UP(int, cl_moff.data(), cl_moff.size(), d_moff) UP(int, mem_cl.data(), mem_cl.size(), d_memcl)
+    int4* d_meminfo;
+    UP(int4, mem_info.data(), mem_info.size(), d_meminfo)
     in.lines = vp::LinesDev{L, d_l0, d_fr0, d_g, d_f, d_z, d_n, d_b, d_v, NCm, d_clfirst, d_clcount, d_clmp, d_clend,
-                            (int)mem_cl.size(), d_moff, d_memcl};
+                            (int)mem_info.size(), d_meminfo};
     vp::InstDev& d = in.dev;
     d.P = P; d.L = L; d.K = Kuse; d.halo_lo = Kuse - 1 - cidx; d.method = voigt_method; d.line_sel = -1;
     d.NCm = NCm;

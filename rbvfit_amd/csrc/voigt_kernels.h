@@ -50,8 +50,8 @@ struct LinesDev {          // static per-instrument line tables (CompiledModelDa
     const int* cl_end;     // per line: one past the last line of its cluster
     // the members of all clusters in a row (prep_lines_kernel forms a cluster's record with one lane per member):
     int M;                 // members of all clusters together
-    const int* cl_moff;    // (NCm + 1) first member of every cluster in that row
-    const int* mem_cl;     // (M) cluster of every member
+    const int4* mem_info;  // (M) per member: cluster, line, first member of the cluster in the row, members of the cluster
+                           // (one 16-byte load: what a member lane needs to find its line tables)
 };
 
 struct FinalizeArgs {      // fused final reduction (last-arriving workgroup of a walker)
@@ -283,10 +283,9 @@ __device__ __forceinline__ void prep_cluster(const double* __restrict__ th, cons
 // accumulator through all members: the last bits of Q_j may differ between the two, both are the same series).
 //   sh: LDS of the wave, 64 x (MPL_STRIDE doubles); j: this lane's member number, n: members, base: lane of member 0.
 constexpr int MPL_STRIDE = 27;        // Q_2..Q_27 of a member (26) + 1: lane stride of 54 banks keeps 8-byte accesses conflict-free
-__device__ __forceinline__ void prep_cluster_lanes(const double* __restrict__ th, const LinesDev& T, int k, int j, int n, int base,
+__device__ __forceinline__ void prep_cluster_lanes(const double* __restrict__ th, const LinesDev& T, int line, int j, int n, int base,
                                                    int lane, bool valid, double* __restrict__ sh, double* __restrict__ rec) {
-    const int first = T.cl_first[k];
-    const LineScalars s = line_scalars(th, T, first + j);
+    const LineScalars s = line_scalars(th, T, line);
     const bool ok = (s.a >= 0.0) && (s.a <= 0.1) && (fabs(s.Tl) <= 1.79e308) && (fabs(s.Ax) <= 1.79e308)
                     && (fabs(s.Bx) <= 1.79e308) && (s.Ax > 0.0);
     const double g0 = s.Bx * fast_rcp(s.Ax);                     // line centre in 1/wave units
@@ -362,7 +361,7 @@ __device__ __forceinline__ void prep_cluster_lanes(const double* __restrict__ th
 //   [0, nb_line)                 line records     index = blockIdx.x * rpw + lane  over (walker, line)
 //   [nb_line, nb_line + nb_cl)   cluster records  one lane per MEMBER, cl_wpw walkers per wave (T.M <= 64 members per walker:
 //                                                 prep_cluster_lanes), or -- cl_wpw = 0 -- one lane per record over (walker, cluster)
-//   the rest                     box-prior flags  one lane per walker
+//   the rest                     box-prior flags  one wave per walker
 // `rpw` (records per wave, <= 64) spreads a small batch over more CUs; lanes >= rpw idle.
 struct PrepGrid { int rpw, nb_line, nb_cl, nb_flag, cl_wpw; };
 __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict__ theta, int W, int D,
@@ -401,8 +400,9 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         const int wl = lane / T.M, mi = lane - wl * T.M, w = blk * G.cl_wpw + wl;
         const bool valid = wl < G.cl_wpw && w < W;
         const int wv = min(w, W - 1), wlv = min(wl, G.cl_wpw - 1);                 // (idle lanes repeat a valid one's work, store nothing)
-        const int k = T.mem_cl[mi], m0 = T.cl_moff[k], n = T.cl_moff[k + 1] - m0;
-        prep_cluster_lanes(theta + (size_t)wv * D, T, k, mi - m0, n, wlv * T.M + m0, lane, valid, sh,
+        const int4 mem = T.mem_info[mi];
+        const int k = mem.x, m0 = mem.z, n = mem.w;
+        prep_cluster_lanes(theta + (size_t)wv * D, T, mem.y, mi - m0, n, wlv * T.M + m0, lane, valid, sh,
                            lc + ((size_t)wv * nrec + T.L + k) * LC_STRIDE);
         return;
     }
@@ -414,13 +414,18 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         return;
     }
     blk -= G.nb_cl;
-    const int w = blk * 64 + lane;                    // ---- box prior (vfit_mcmc.py:291-295, 350-351) ----
+    // ---- box prior (vfit_mcmc.py:291-295, 350-351): one WAVE per walker, the parameters across its lanes (a lane per
+    //      walker walked its D parameters one load after the other -- 13 us of the launch at D = 96)
+    const int w = blk;
     if (!do_flags || w >= W) return;
     const double* th = theta + (size_t)w * D;
-    int oob = 0;
-    for (int d = 0; d < D; ++d) oob |= (th[d] < lb[d]) || (th[d] > ub[d]);
-    flags[w] = oob;
-    if (oob && lnprob_out) lnprob_out[w] = -__builtin_inf();
+    bool oob = false;
+    for (int d = lane; d < D; d += 64) oob = oob || (th[d] < lb[d]) || (th[d] > ub[d]);
+    const bool any = __ballot(oob) != 0ull;
+    if (lane == 0) {
+        flags[w] = any ? 1 : 0;
+        if (any && lnprob_out) lnprob_out[w] = -__builtin_inf();
+    }
 }
 
 // Test hook: records for a list of damping parameters with T = 1.
