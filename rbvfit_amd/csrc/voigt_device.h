@@ -134,28 +134,36 @@ __device__ __forceinline__ double exp_neg(double t) {
     return __builtin_ldexp(p, (int)n);
 }
 
-// Table-driven exp(-t), t >= 0: n = rint(-t * 64/ln2), r = -t - n ln2/64 (|r| <= 0.0054), result =
-// 2^(n>>6) * T[n&63] * (1 + r + ... + r^5/120).  T = 2^(j/64) staged in LDS (per-lane gather, 64
-// entries).  ~16 VALU instructions instead of ~45 for the polynomial version (whose 14 literal
-// coefficients each cost extra v_mov's); relative error ~2e-16.
-constexpr int EXP_LDS_DOUBLES = 64;
+// Table-driven exp(-t), t >= 0: n = rint(-t * 8/ln2), r = -t - n ln2/8 (|r| <= 0.0434), result =
+// 2^(n>>3) * T[n&7] * (1 + r + ... + r^8/8!) (truncation 1.5e-18).  T = 2^(j/8) staged in LDS (per-lane gather).
+// ~19 VALU instructions instead of ~45 for the polynomial version (whose 14 literal coefficients each cost extra
+// v_mov's); relative error ~2e-16.  Eight entries, not 64 with a degree-5 polynomial: three more FMAs per call buy 448 B of
+// LDS per tile, which (with the Dawson table below) is the difference between five and four allocation granules of
+// 1280 B per single-wave tile workgroup -- 25 against 28 (register-limited) tiles per CU, and the tile launches run as fast
+// as the CUs are full (profiles/r03_notes.md).
+constexpr int EXP_LDS_DOUBLES = 8;
+constexpr double LN2_8_HI = 8.0 * LN2_64_HI, LN2_8_LO = 8.0 * LN2_64_LO, INV_LN2_8 = INV_LN2_64 / 8.0;   // (exact scalings)
+__device__ __forceinline__ double exp2_eighth(int j) { return g_exp2_64[8 * j]; }       // 2^(j/8), j < 8
 __device__ __forceinline__ void exp_table_to_lds(double* __restrict__ et, int tid, int nthreads) {
-    for (int j = tid; j < EXP_LDS_DOUBLES; j += nthreads) et[j] = g_exp2_64[j];
+    for (int j = tid; j < EXP_LDS_DOUBLES; j += nthreads) et[j] = exp2_eighth(j);
 }
 __device__ __forceinline__ double exp_neg_tab(double t, const double* __restrict__ et) {
     const double x = -fmin(t, 800.0);
-    const double n = __builtin_rint(x * INV_LN2_64);
-    double r = __builtin_fma(n, -LN2_64_HI, x);
-    r = __builtin_fma(n, -LN2_64_LO, r);
+    const double n = __builtin_rint(x * INV_LN2_8);
+    double r = __builtin_fma(n, -LN2_8_HI, x);
+    r = __builtin_fma(n, -LN2_8_LO, r);
     const int ni = (int)n;
-    const double tj = et[ni & 63];
-    double p = 8.33333333333333333333e-03;                 // 1/120
+    const double tj = et[ni & 7];
+    double p = 2.48015873015873015873e-05;                 // 1/8!
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);   // 1/7!
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);   // 1/6!
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);   // 1/120
     p = __builtin_fma(p, r, 4.16666666666666666667e-02);
     p = __builtin_fma(p, r, 1.66666666666666666667e-01);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    return __builtin_ldexp(tj * p, ni >> 6);
+    return __builtin_ldexp(tj * p, ni >> 3);
 }
 
 // x as the reference rounds it (voigt_model.py:204,144,150) without divisions:
@@ -252,7 +260,7 @@ __device__ __forceinline__ double core_taylor_H(double x, double a, double ea2, 
         F = __builtin_fma(F, t, cf[k]);
         G = __builtin_fma(G, t, cf[DAW_DEG + 1 + k]);
     }
-    G = (i >= DAW_GLO) ? G : __builtin_fma(-2.0 * ax, F, 1.0);   // same rule as the LDS version below
+    G = (i >= DAW_GLO) ? G : __builtin_fma(-2.0 * ax, F, 1.0);   // (the LDS version below forms G from F everywhere)
     const double c = 1.1283791670955125739;          // 2/sqrt(pi)
     double vp = c * F, vc = c * G;                    // v_0, v_1
     const double E = exp_neg(ax * ax);
@@ -275,25 +283,16 @@ __device__ __forceinline__ double core_taylor_H(double x, double a, double ea2, 
     return __builtin_fma(E * ea2, cos_small(2.0 * a * ax), acc);
 }
 
-// Same series with the Dawson tables staged in LDS; used by the tile kernel's hot loop.
-// LDS copy of the Dawson tables: F for all 16 intervals, G = 1 - 2xF only for |x| >= 5 (intervals
-// DAW_GLO..15).  Below that G is formed from F: its absolute error stays ~1.5e-16, which is what enters H
-// (through a*(2/sqrt(pi))*G, next to a Gaussian term >= 1.4e-11) -- relative effect on H below 8e-15;
-// beyond |x| = 5, where H is the a-term alone, the subtraction would cost up to 2x^2 = 128 ulp of G, and
-// G has its own polynomial.  308 doubles instead of 448: with it a
-// single-wave workgroup fits in 6400 B of LDS (5 allocation granules) -> 6 waves per SIMD.
+// Same series with the Dawson table staged in LDS; used by the tile kernel's hot loop.
+// LDS copy: F for all 16 intervals; G = 1 - 2xF is formed from it.  Up to |x| = 5 its absolute error stays ~1.5e-16, which is
+// what enters H (through a*(2/sqrt(pi))*G, next to a Gaussian term >= 1.4e-11): relative effect on H below 8e-15.  Beyond,
+// where H is the a-term alone, the subtraction costs up to 2x^2 = 128 ulp of G: 1.4e-14 relative on H at |x| = 8, against a
+// contract of 1e-12 (the global-memory form above keeps G's own polynomial there; an LDS copy of it was 84 doubles of every
+// tile workgroup -- see exp_neg_tab on what LDS per tile costs).
 constexpr int DAW_F_DOUBLES = DAW_NI * (DAW_DEG + 1);
-constexpr int DAW_LDS_DOUBLES = DAW_F_DOUBLES + (DAW_NI - DAW_GLO) * (DAW_DEG + 1);
+constexpr int DAW_LDS_DOUBLES = DAW_F_DOUBLES;
 __device__ __forceinline__ void dawson_to_lds(double* __restrict__ daw, int tid, int nthreads) {
-    for (int idx = tid; idx < DAW_LDS_DOUBLES; idx += nthreads) {
-        double v;
-        if (idx < DAW_F_DOUBLES) v = g_dawson[idx / (DAW_DEG + 1)][0][idx % (DAW_DEG + 1)];
-        else {
-            const int j = idx - DAW_F_DOUBLES;
-            v = g_dawson[DAW_GLO + j / (DAW_DEG + 1)][1][j % (DAW_DEG + 1)];
-        }
-        daw[idx] = v;
-    }
+    for (int idx = tid; idx < DAW_LDS_DOUBLES; idx += nthreads) daw[idx] = g_dawson[idx / (DAW_DEG + 1)][0][idx % (DAW_DEG + 1)];
 }
 // N independent pixels per lane for ONE line (a, ea2, nodd wave-uniform): the stages of the N evaluations sit side
 // by side in one basic block, so that a wave that is alone on its SIMD overlaps their dependent chains.  Every
@@ -304,13 +303,11 @@ __device__ __forceinline__ void core_taylor_H_lds_n(const double (&x)[N], double
                                                     double (&H)[N]) {
     double ax[N], t[N], F[N], G[N];
     int i[N];
-    bool hi = false;
 #pragma unroll
     for (int r = 0; r < N; ++r) {
         ax[r] = fabs(x[r]);
         i[r] = min((int)(ax[r] * 2.0), DAW_NI - 1);
         t[r] = __builtin_fma(ax[r], 4.0, -(double)(2 * i[r] + 1));
-        hi = hi || (i[r] >= DAW_GLO);
     }
     {
         const double* __restrict__ cF[N];
@@ -324,19 +321,6 @@ __device__ __forceinline__ void core_taylor_H_lds_n(const double (&x)[N], double
     }
 #pragma unroll
     for (int r = 0; r < N; ++r) G[r] = __builtin_fma(-2.0 * ax[r], F[r], 1.0);
-    if (__ballot(hi) != 0ull) {                       // some lane beyond |x| = 5: G from its own polynomial there
-        const double* __restrict__ cG[N];
-        double Gt[N];
-#pragma unroll
-        for (int r = 0; r < N; ++r) { cG[r] = daw + DAW_F_DOUBLES + max(i[r] - DAW_GLO, 0) * (DAW_DEG + 1); Gt[r] = cG[r][DAW_DEG]; }
-#pragma unroll
-        for (int k = DAW_DEG - 1; k >= 0; --k) {
-#pragma unroll
-            for (int r = 0; r < N; ++r) Gt[r] = __builtin_fma(Gt[r], t[r], cG[r][k]);
-        }
-#pragma unroll
-        for (int r = 0; r < N; ++r) G[r] = (i[r] >= DAW_GLO) ? Gt[r] : G[r];
-    }
     const double c = 1.1283791670955125739;          // 2/sqrt(pi)
     double vp[N], vc[N], E[N], acc[N];
     const double a2 = a * a;

@@ -992,7 +992,7 @@ __device__ __forceinline__ TilePre tile_preload(const InstDev& I, int p0, int no
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
     TilePre pre;
-    pre.e2 = g_exp2_64[tid & 63];
+    pre.e2 = exp2_eighth(tid & 7);
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int i = min(wid * (64 * RB) + r * 64 + lane, n_eval - 1);
@@ -1151,7 +1151,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     unsigned long long* __restrict__ cmask = reinterpret_cast<unsigned long long*>(etab + EXP_LDS_DOUBLES);
     const int nwords = (I.L + 63) >> 6;                // 64 lines per mask word
     const int nchunks = (n_eval + 63) >> 6;
-    if (first && tid < EXP_LDS_DOUBLES) etab[tid] = PRE ? pre.e2 : g_exp2_64[tid];
+    if (first && tid < EXP_LDS_DOUBLES) etab[tid] = PRE ? pre.e2 : exp2_eighth(tid);
     if (tid < FL_PAD) fl[n_eval + tid] = 0.0;   // what the zero taps multiply must be finite
     // Multi-wave tiles: the exp table is staged by the first wave and read by ALL waves at the end of their first pass.
     // A pass used to be long enough for that never to matter; with the far-field expansions a pass over a block
@@ -1745,7 +1745,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     const int p0 = lt * I.TP, nout = min(p0 + I.TP, I.P) - p0;
     VP_STAMP(10);
     const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
-    fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = g_exp2_64[lane];   // the wave's exp table (EXP_LDS_DOUBLES = 64 entries),
+    if (lane < EXP_LDS_DOUBLES) fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = exp2_eighth(lane);   // the wave's exp table,
                                                                            // staged while it waits for the records anyway
     // ... and the Dawson table where the tile met line cores before (1.2 us between phase A and phase B otherwise)
     const bool daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(I.core_hint[lt]) != 0;
