@@ -290,11 +290,35 @@ def rank_main(args):
     def launch(out):
         eng.lnprob_device(d_theta.data_ptr(), out.data_ptr(), W, stream.cuda_stream)
 
-    def strict_step():
+    def rccl_step():
         """One pass of a single W_total-walker ensemble: local block, then every rank gets the whole vector."""
         launch(d_out)
         if use_dist:
             dist.all_gather_into_tensor(gathered, d_out)
+
+    # The exchange of the strict form: the lnprob launch itself writes the rank's block into every rank's gathered vector
+    # (rbvfit_amd.dist.DirectGather, vp_gather_*: peer-mapped stores + one flag per rank, the next pass waits on the device),
+    # where the batch runs as one launch and the runtime shares device memory between the ranks; the blocking RCCL
+    # all_gather otherwise (BENCH_GATHER=rccl forces it).  DirectGather.probe checks two passes against the collective.
+    direct = None
+    direct_reason = "not a multi-rank run"
+    if use_dist:
+        if os.environ.get("BENCH_GATHER", "direct") == "rccl":
+            direct_reason = "BENCH_GATHER=rccl"
+        else:
+            from rbvfit_amd.dist import DirectGather
+            direct = DirectGather.probe(eng, d_theta)
+            direct_reason = DirectGather.last_reason
+
+    def strict_step():
+        if direct is not None:
+            direct.step(stream.cuda_stream)
+        else:
+            rccl_step()
+
+    def strict_drain():
+        if direct is not None:
+            direct.wait(stream.cuda_stream)         # (the last pass's blocks have landed everywhere inside the timed region)
 
     def timed(fn, n, drain=None):
         if use_dist:
@@ -322,12 +346,22 @@ def rank_main(args):
     # The GPU needs ~25 ms of sustained load to reach its steady clocks (scripts/warm_probe.py: 37.9 us
     # per step in the first 8 ms after an idle period, 32.9 us from ~25 ms on); a sampler runs for
     # minutes, so the untimed part is made long enough whatever --warmup says (>= 50 ms of passes).
-    t_probe = timed(strict_step, 10) / 10
+    t_probe = timed(strict_step, 10, strict_drain) / 10
     warm_eff = max(args.warmup, int(min(1500, max(20, 0.05 / max(t_probe, 1e-6)))))
     for _ in range(warm_eff):
         strict_step()
     repeats = args.repeats if args.repeats > 0 else int(min(200, max(3, np.ceil(0.25 / max(args.steps * t_probe, 1e-9)))))
-    elapsed, block_times = blocks(strict_step, args.steps, repeats)
+    elapsed, block_times = blocks(strict_step, args.steps, repeats, drain=strict_drain)
+    rccl_ms = None
+    if direct is not None:
+        torch.cuda.synchronize()
+        if direct.timed_out():
+            raise SystemExit("bench.py: a device-side wait of the direct gather timed out")
+        launch(d_out)
+        torch.cuda.synchronize()
+        me = direct.gathered[rank * W:(rank + 1) * W]
+        assert torch.equal(torch.nan_to_num(me), torch.nan_to_num(d_out)), "direct gather differs from the local block"
+        rccl_ms = 1e3 * blocks(rccl_step, args.steps, min(repeats, 20))[0] / args.steps       # the collective beside it
 
     # island form (rbvfit_amd.dist): a rank's accept/reject needs its own lnprob only, so the all-gather of a
     # chunk of steps runs on RCCL's stream, double-buffered, under the next chunk's kernels; and the gather-free
@@ -535,7 +569,8 @@ def rank_main(args):
             "config": {"workload": WORKLOAD_LABEL[args.config],
                        "walkers_per_gpu": W, "walkers_total": W * world, "ndim": D, "n_lines": wl.n_lines,
                        "pixels": wl.pixels,
-                       "parallelism": f"walker-shard x{world}" + (" + blocking RCCL all_gather per pass" if world > 1 else "")},
+                       "parallelism": f"walker-shard x{world}" + ((" + direct-write gather per pass" if direct is not None else
+                                                                   " + blocking RCCL all_gather per pass") if world > 1 else "")},
             "passes_per_sec": args.steps / elapsed,
             "mcmc_steps_per_sec": sampler_steps,
             "mcmc_steps_per_sec_note": "device-resident stretch move (vp_stretch_run): one ensemble step = two half-ensemble "
@@ -554,7 +589,12 @@ def rank_main(args):
             "roofline": roof,
         }
         if use_dist:
-            line["gather"] = {"value_form": "strict: blocking all_gather_into_tensor of the per-walker lnprob after every pass",
+            line["gather"] = {"value_form": ("strict: every pass's lnprob block written by the launch itself into every rank's gathered "
+                                             "vector (peer-mapped stores, one flag per rank; the next pass waits for it on the device): "
+                                             "rbvfit_amd.dist.DirectGather / vp_gather_*") if direct is not None else
+                                            "strict: blocking all_gather_into_tensor of the per-walker lnprob after every pass",
+                              "direct_gather": direct is not None, "direct_gather_unavailable_because": direct_reason or None,
+                              "ms_per_step_blocking_rccl_all_gather": rccl_ms,
                               "ms_per_step_island_form": island_ms,
                               "island_form": f"async all_gather_into_tensor of {gather_every}-step chunks, double-buffered, "
                                              "overlapped with the following passes (rbvfit_amd.dist.PipelinedGather)",

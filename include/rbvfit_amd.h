@@ -100,6 +100,28 @@ int vp_lnprob_batch(vp_ctx* ctx, int W, int D, const double* theta, double* out)
 int vp_lnprob_batch_device(vp_ctx* ctx, int W, int D, const double* d_theta, double* d_out,
                            void* hip_stream);
 
+/* ---- direct-write gather: the per-pass exchange of a walker-sharded ensemble, one process per GPU ----
+ * Replaces, for the one-launch batches, the collective behind every pass of the reference's fan-out (vfit_mcmc.py:35-49,
+ * 408-440: every worker's results return to the sampler): each rank owns a (world, W) vector of device memory that its peers
+ * map (hipIpc handles, carried by the job's own channel -- rbvfit_amd.dist.DirectGather uses torch.distributed's object
+ * all-gather).  vp_lnprob_gather_device is vp_lnprob_batch_device with the output written by the kernel itself into this rank's
+ * block of EVERY rank's vector (8 bytes per walker and rank) and published by the launch's last workgroup; the next pass's
+ * workgroups start by waiting, on the device, for their peers' blocks of the pass before -- the dependency a blocking all-gather
+ * states, without a collective launch or a host wait.  Only batches that run as ONE walker_kernel launch (VP_ESTATE otherwise:
+ * use vp_lnprob_batch_device and the collective).
+ *   vp_gather_create    allocates this rank's vector and flags; handles_out: 2 x 64 bytes (hipIpcMemHandle_t of both), zeros
+ *                       when world == 1.  1 <= world <= 8.
+ *   vp_gather_connect   handles_all: world x 2 x 64 bytes, rank-major (this rank's own entry is not opened).
+ *   vp_gather_wait      enqueues a one-wave kernel that returns once every rank's block of the LAST pass has landed here.
+ *   vp_gather_state     the device pointer of this rank's (world, W) vector; *timed_out != 0 if a device-side wait gave up
+ *                       (~ a second of polling: a peer that never ran), synchronises.  Either pointer may be NULL. */
+int vp_gather_create(vp_ctx* ctx, int W, int world, int rank, void* handles_out);
+int vp_gather_connect(vp_ctx* ctx, const void* handles_all);
+int vp_lnprob_gather_device(vp_ctx* ctx, int W, int D, const double* d_theta, void* hip_stream);
+int vp_gather_wait(vp_ctx* ctx, void* hip_stream);
+int vp_gather_state(vp_ctx* ctx, double** d_gathered, int* timed_out);
+int vp_gather_destroy(vp_ctx* ctx);
+
 /* Model flux for a batch.  Replaces: CompiledVoigtModel.model_flux per row
  * (core/voigt_model.py:295-311).  out is row-major (W, P) host memory.  convolved = 0 returns the
  * profile before the LSF (VoigtModel.evaluate(return_unconvolved=True), :509-558).  The prior is

@@ -55,6 +55,7 @@ struct Tuning {
                                 // (0: hipStreamSynchronize; measured 512-walker C1 call 42.7 -> ~33 us)
     int no_ff_members = 0;      // (read when an instrument is added) never take cluster members into the far-field expansions one by one
     int tile_multi = -1;        // tiles of several instruments in one launch (tile_kernel_multi): -1 by batch size, 0 never, 1 whenever possible
+    int gather_plain = 0;       // vp_gather_create: ordinary device memory for the gathered vector and flags instead of fine-grained
     int tile_lpt = 1;           // (read when an instrument is added) tile launches hand out the tiles with the most line cores
                                 // first (0: in grid order)
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
@@ -72,7 +73,7 @@ const Knob g_knobs[] = {
     VP_KNOB(span, "RBVFIT_AMD_SPAN", 0), VP_KNOB(waves, "RBVFIT_AMD_WAVES", 0), VP_KNOB(lds_pad, "RBVFIT_AMD_LDS_PAD", 1),
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
-    VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
+    VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -153,6 +154,16 @@ struct vp_ctx {
     uint32_t* h_done = nullptr;
     uint32_t done_seq = 0;
     bool done_armed = false;     // the last batch enqueued carries a completion write
+    // direct-write gather of the lnprob vector between the ranks of a multi-process job (vp_gather_*)
+    struct Gather {
+        int W = 0, world = 0, rank = 0, seq = 0;
+        bool connected = false, finegrained = false;
+        double* buf = nullptr;                 // (world, W) this rank's gathered vector
+        int* flags = nullptr;                  // (MAX_REPLICAS) flags[r] = the last pass whose block from rank r has landed here
+        unsigned int* done = nullptr;          // workgroup counters of the running launch (PUB_GROUPS + 1) | timeout flag (int)
+        double* peer_buf[vp::MAX_REPLICAS] = {};
+        int* peer_flags[vp::MAX_REPLICAS] = {};
+    } gather;
     // model_flux / voigt_h scratch
     double* d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -447,9 +458,11 @@ void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::Stre
     else hipLaunchKernelGGL((vp::walker_kernel<0, false, SAMPLER>), grid, block, lds, s, d0, t0, a, st);
 }
 
-void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s) {
+void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s, const vp::Replicas* gather = nullptr) {
     const vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double))};
-    launch_walker_any<false>(c, W, a, vp::StretchArgs{}, s);
+    vp::StretchArgs st{};
+    if (gather) st.rep = *gather;            // (the plain form's only use of the sampler arguments: where the results go)
+    launch_walker_any<false>(c, W, a, st, s);
 }
 
 // One stretch-move half-step of the active half (nS walkers) as ONE launch: proposal, lnprob and accept/reject inside
@@ -690,6 +703,20 @@ int vp_set_option(vp_ctx* c, const char* name, long value) {
     return fail(c, VP_EINVAL, std::string("vp_set_option: unknown option '") + name + "'");
 }
 
+static void gather_release(vp_ctx* c) {
+    vp_ctx::Gather& g = c->gather;
+    for (int r = 0; r < g.world && r < vp::MAX_REPLICAS; ++r) {
+        if (r == g.rank) continue;
+        if (g.peer_buf[r]) (void)hipIpcCloseMemHandle(g.peer_buf[r]);
+        if (g.peer_flags[r]) (void)hipIpcCloseMemHandle(g.peer_flags[r]);
+    }
+    if (g.buf) (void)hipFree(g.buf);
+    if (g.flags) (void)hipFree(g.flags);
+    if (g.done) (void)hipFree(g.done);
+    (void)hipGetLastError();
+    g = vp_ctx::Gather{};
+}
+
 int vp_ctx_destroy(vp_ctx* c) {
     if (!c) return VP_OK;
     hipSetDevice(c->device);
@@ -701,6 +728,7 @@ int vp_ctx_destroy(vp_ctx* c) {
         if (p) hipFree(p);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_done) hipHostFree(c->h_done);
+    gather_release(c);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1019,6 +1047,171 @@ int vp_lnprob_batch_device(vp_ctx* c, int W, int D, const double* d_theta, doubl
     if ((rc = ensure_workspace(c, W))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     return enqueue_lnprob(c, W, d_theta, d_out, s);
+}
+
+// ---- direct-write gather (the per-pass exchange of the walker sharding) ---------------------------------
+// One process per GPU: every rank owns a (world, W) vector and the flags of its peers' passes; the memory is exported with
+// hipIpcGetMemHandle, the handles travel through the job's own channel (torch.distributed's object all-gather in
+// rbvfit_amd.dist.DirectGather) and every rank maps its peers' vectors.  A pass is then ONE launch: walker_kernel stores each
+// walker's lnprob into its block of every rank's vector (8 bytes per walker and rank, through the mapped pointers); the next
+// launch on the stream raises this rank's flag in every peer -- the pass before is complete when it starts -- and its workgroups
+// wait for their peers' flags of that pass before they compute (vp::replicas_handshake): no collective launch, no host
+// involvement, nothing counted at the end of a launch.
+namespace { __global__ void gather_wait_kernel(vp::Replicas R) { vp::replicas_handshake(R); } }
+
+static vp::Replicas gather_replicas(const vp_ctx* c, int seq) {
+    const vp_ctx::Gather& g = c->gather;
+    vp::Replicas R{};
+    R.n = g.world;
+    for (int r = 0; r < g.world; ++r) {
+        R.pos[r] = nullptr;
+        R.lp[r] = (r == g.rank ? g.buf : g.peer_buf[r]) + (size_t)g.rank * g.W;
+        R.flags[r] = r == g.rank ? g.flags : g.peer_flags[r];
+    }
+    R.done = g.done;
+    R.timeout = reinterpret_cast<int*>(g.done + vp::PUB_GROUPS + 1);
+    R.me = g.rank;
+    R.seq = seq;
+    R.sync = g.world > 1 ? 2 : 1;
+    return R;
+}
+
+int vp_gather_create(vp_ctx* c, int W, int world, int rank, void* handles_out) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (W <= 0 || world <= 0 || world > vp::MAX_REPLICAS || rank < 0 || rank >= world || !handles_out)
+        return fail(c, VP_EINVAL, "vp_gather_create: W > 0, 1 <= world <= " + std::to_string(vp::MAX_REPLICAS) + ", 0 <= rank < world and a handle buffer required");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    gather_release(c);
+    vp_ctx::Gather& G = c->gather;
+    G.W = W; G.world = world; G.rank = rank;
+    const size_t bb = (size_t)world * W * sizeof(double), fb = 64 * sizeof(int);
+    // fine-grained device memory where the runtime offers it (peers write while kernels here read), plain otherwise
+    if (!c->tune.gather_plain && hipExtMallocWithFlags((void**)&G.buf, bb, hipDeviceMallocFinegrained) == hipSuccess &&
+        hipExtMallocWithFlags((void**)&G.flags, fb, hipDeviceMallocFinegrained) == hipSuccess) {
+        G.finegrained = true;
+    } else {
+        (void)hipGetLastError();
+        if (G.buf) { (void)hipFree(G.buf); G.buf = nullptr; }
+        if (G.flags) { (void)hipFree(G.flags); G.flags = nullptr; }
+        HIP_TRY(c, hipMalloc((void**)&G.buf, bb));
+        HIP_TRY(c, hipMalloc((void**)&G.flags, fb));
+    }
+    HIP_TRY(c, hipMalloc((void**)&G.done, 128));
+    HIP_TRY(c, hipMemset(G.buf, 0, bb));
+    HIP_TRY(c, hipMemset(G.flags, 0, fb));
+    HIP_TRY(c, hipMemset(G.done, 0, 128));
+    HIP_TRY(c, hipDeviceSynchronize());
+    std::memset(handles_out, 0, 2 * sizeof(hipIpcMemHandle_t));
+    if (world > 1) {
+        hipIpcMemHandle_t h[2];
+        hipError_t e = hipIpcGetMemHandle(&h[0], G.buf);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&h[1], G.flags);
+        if (e != hipSuccess && G.finegrained) {          // (fine-grained memory that cannot be exported: plain memory instead)
+            (void)hipGetLastError();
+            (void)hipFree(G.buf); (void)hipFree(G.flags);
+            G.buf = nullptr; G.flags = nullptr; G.finegrained = false;
+            HIP_TRY(c, hipMalloc((void**)&G.buf, bb));
+            HIP_TRY(c, hipMalloc((void**)&G.flags, fb));
+            HIP_TRY(c, hipMemset(G.buf, 0, bb));
+            HIP_TRY(c, hipMemset(G.flags, 0, fb));
+            HIP_TRY(c, hipDeviceSynchronize());
+            e = hipIpcGetMemHandle(&h[0], G.buf);
+            if (e == hipSuccess) e = hipIpcGetMemHandle(&h[1], G.flags);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            gather_release(c);
+            return fail(c, VP_EHIP, std::string("vp_gather_create: hipIpcGetMemHandle: ") + hipGetErrorString(e));
+        }
+        std::memcpy(handles_out, h, sizeof(h));
+    } else {
+        G.connected = true;
+    }
+    return VP_OK;
+}
+
+int vp_gather_connect(vp_ctx* c, const void* handles_all) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    vp_ctx::Gather& G = c->gather;
+    if (!G.buf) return fail(c, VP_ESTATE, "vp_gather_connect: call vp_gather_create first");
+    if (G.connected) return VP_OK;
+    if (!handles_all) return fail(c, VP_EINVAL, "vp_gather_connect: NULL handles");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const hipIpcMemHandle_t* h = static_cast<const hipIpcMemHandle_t*>(handles_all);
+    for (int r = 0; r < G.world; ++r) {
+        if (r == G.rank) continue;
+        void *pb = nullptr, *pf = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&pb, h[2 * r], hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf, h[2 * r + 1], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (pb) (void)hipIpcCloseMemHandle(pb);
+            return fail(c, VP_EHIP, std::string("vp_gather_connect: hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
+        }
+        G.peer_buf[r] = static_cast<double*>(pb);
+        G.peer_flags[r] = static_cast<int*>(pf);
+    }
+    G.connected = true;
+    return VP_OK;
+}
+
+int vp_lnprob_gather_device(vp_ctx* c, int W, int D, const double* d_theta, void* hip_stream) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    vp_ctx::Gather& G = c->gather;
+    if (!G.connected) return fail(c, VP_ESTATE, "vp_lnprob_gather_device: no connected gather (vp_gather_create / vp_gather_connect)");
+    int rc = check_batch_args(c, W, D, d_theta, G.buf);
+    if (rc) return rc;
+    if (W != G.W) return fail(c, VP_EINVAL, "vp_lnprob_gather_device: W differs from the gather's block size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_workspace(c, W))) return rc;
+    if (!walker_applies(c, c->policy_W > 0 ? c->policy_W : W))
+        return fail(c, VP_ESTATE, "vp_lnprob_gather_device: this batch does not run as one walker_kernel launch (use vp_lnprob_batch_device and a collective)");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const vp::Replicas R = gather_replicas(c, ++G.seq);
+    c->last_kind = 1;
+    launch_walker(c, W, d_theta, nullptr, s, &R);
+    HIP_TRY(c, hipGetLastError());
+    return VP_OK;
+}
+
+int vp_gather_wait(vp_ctx* c, void* hip_stream) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    vp_ctx::Gather& G = c->gather;
+    if (!G.connected) return fail(c, VP_ESTATE, "vp_gather_wait: no connected gather");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipLaunchKernelGGL(gather_wait_kernel, dim3(1), dim3(64), 0, s, gather_replicas(c, G.seq + 1));
+    HIP_TRY(c, hipGetLastError());
+    return VP_OK;
+}
+
+int vp_gather_state(vp_ctx* c, double** d_gathered, int* timed_out) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    vp_ctx::Gather& G = c->gather;
+    if (!G.buf) return fail(c, VP_ESTATE, "vp_gather_state: no gather");
+    if (d_gathered) *d_gathered = G.buf;
+    if (timed_out) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        int t = 0;
+        HIP_TRY(c, hipMemcpy(&t, G.done + vp::PUB_GROUPS + 1, sizeof(int), hipMemcpyDeviceToHost));     // (synchronises with the stream's work)
+        *timed_out = t;
+    }
+    return VP_OK;
+}
+
+int vp_gather_destroy(vp_ctx* c) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    gather_release(c);
+    return VP_OK;
 }
 
 // (called with c->mu held) host-buffer lnprob in two halves, so that several contexts (vp_multi) can have their
@@ -1841,15 +2034,16 @@ int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob,
         if ((rc = ensure_workspace(c, std::max(W, per)))) return multi_fail(m, i, rc);
         const size_t nchain = (flags_mode || i == 0) ? chunk * row : 0;
         const size_t nd = (size_t)W * D + W + (size_t)per * D + 2 * (size_t)per + nchain;
-        if ((rc = ensure_scratch(c, nd * sizeof(double) + (size_t)W * sizeof(long long) + (vp::MAX_REPLICAS + 4) * sizeof(int) + 64))) return multi_fail(m, i, rc);
+        if ((rc = ensure_scratch(c, nd * sizeof(double) + (size_t)W * sizeof(long long) + (vp::MAX_REPLICAS + 4 + vp::PUB_GROUPS + 1) * sizeof(int) + 64))) return multi_fail(m, i, rc);
         Dev& d = dv[i];
         d.pos = c->d_scratch; d.lp = d.pos + (size_t)W * D; d.prop = d.lp + W; d.lpnew = d.prop + (size_t)per * D;
         d.zz = d.lpnew + per; d.chain = d.zz + per;
         d.nacc = reinterpret_cast<long long*>(d.chain + nchain);
         d.nan = reinterpret_cast<int*>(d.nacc + W);
-        d.flags = d.nan + 1; d.done = reinterpret_cast<unsigned int*>(d.flags + vp::MAX_REPLICAS); d.timeout = reinterpret_cast<int*>(d.done + 1);
+        d.flags = d.nan + 1; d.done = reinterpret_cast<unsigned int*>(d.flags + vp::MAX_REPLICAS);      // (PUB_GROUPS + 1 counters)
+        d.timeout = reinterpret_cast<int*>(d.done + vp::PUB_GROUPS + 1);
         MTRY(hipMemcpyAsync(d.pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        MTRY(hipMemsetAsync(d.nacc, 0, (size_t)W * sizeof(long long) + (vp::MAX_REPLICAS + 4) * sizeof(int), c->stream));
+        MTRY(hipMemsetAsync(d.nacc, 0, (size_t)W * sizeof(long long) + (vp::MAX_REPLICAS + 4 + vp::PUB_GROUPS + 1) * sizeof(int), c->stream));
         if (have_lnprob) MTRY(hipMemcpyAsync(d.lp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, c->stream));
         else {
             // every replica evaluates the whole start state itself (once per run; the same launches as vp_stretch_run's)

@@ -171,22 +171,54 @@ __device__ __forceinline__ void replicas_wait(const Replicas& R) {
 }
 
 // one thread per workgroup, behind the workgroup's last store into the replicas: the last workgroup of the grid
-// publishes the half-step to every replica
+// publishes the half-step to every replica.  The workgroups are counted in PUB_GROUPS groups (by index) whose last members
+// count once more on a top word: 512 returning atomics on ONE word took the tail of a launch ~10 us (a word serves ~90 of them
+// per microsecond), 16 words of 32 do not queue.  R.done: PUB_GROUPS group counters, then the top one.
+constexpr unsigned int PUB_GROUPS = 16;
 __device__ __forceinline__ void replicas_publish(const Replicas& R, unsigned int nworkgroups) {
     if (!R.sync) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // this workgroup's rows before its count
-    const unsigned int old = __hip_atomic_fetch_add(R.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == nworkgroups - 1u) {
-        __hip_atomic_store(R.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (R.sync == 2) {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");       // every workgroup's rows, out of this device's L2, before the flags
-            for (int p = 0; p < R.n; ++p)
-                __hip_atomic_store(R.flags[p] + R.me, R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            for (int p = 0; p < R.n; ++p)
-                __hip_atomic_store(R.flags[p] + R.me, R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int g = blockIdx.x % PUB_GROUPS, ngroups = nworkgroups < PUB_GROUPS ? nworkgroups : PUB_GROUPS;
+    const unsigned int members = (nworkgroups - g + PUB_GROUPS - 1u) / PUB_GROUPS;          // workgroups w < nworkgroups with w % 16 == g
+    if (__hip_atomic_fetch_add(R.done + g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != members - 1u) return;
+    __hip_atomic_store(R.done + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(R.done + PUB_GROUPS, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != ngroups - 1u) return;
+    __hip_atomic_store(R.done + PUB_GROUPS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (R.sync == 2) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");           // every workgroup's rows, out of this device's L2, before the flags
+        for (int p = 0; p < R.n; ++p)
+            __hip_atomic_store(R.flags[p] + R.me, R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        for (int p = 0; p < R.n; ++p)
+            __hip_atomic_store(R.flags[p] + R.me, R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Ordering for the direct-write gather of lnprob batches (vp_gather_*), whose passes are whole launches on one stream: a
+// launch's stores into the peers' vectors (system-scope atomic stores: no cache holds them) are complete when the launch is, so
+// the NEXT launch on the stream can vouch for them -- its first workgroup raises this rank's flag in every peer to the pass
+// before, then all its workgroups wait for the peers' flags of that pass before they compute.  No count of finished
+// workgroups, no fence, nothing at the end of a launch: a count (a returning device-scope atomic or two per workgroup behind its
+// last store) cost the tail of a 512-workgroup launch 5.5 us, release fences in front of it -- L2 write-backs on a GPU of eight
+// L2s -- 11 us; a blocking RCCL all_gather 9 us.
+// all lanes of every wave; R.seq = the pass this launch computes (the flags of pass R.seq - 1 are raised and awaited)
+__device__ __forceinline__ void replicas_handshake(const Replicas& R) {
+    if (R.seq <= 1 || R.n <= 1) return;
+    const int lane = threadIdx.x & 63;
+    const int need = R.seq - 1;
+    if (blockIdx.x == 0 && threadIdx.x < 64 && lane < R.n && lane != R.me)
+        __hip_atomic_store(R.flags[lane] + R.me, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int spins = 0;
+    for (;;) {
+        int f = need;
+        if (lane < R.n && lane != R.me) f = __hip_atomic_load(R.flags[R.me] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__ballot(f < need) == 0ull) break;
+        if (++spins > SYNC_SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_store(R.timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
         }
+        __builtin_amdgcn_s_sleep(8);
     }
 }
 

@@ -1644,6 +1644,20 @@ struct WalkerArgs {
     int wave_lds;          // LDS doubles per wave (= per tile)
 };
 
+// Where a walker's lnprob goes (one thread per workgroup): the batch's output vector, and -- direct-write gather of a
+// multi-rank job, R.n > 0 -- this rank's block of the gathered vector of EVERY rank (R.lp[r], peer-mapped, 8 bytes per walker
+// and rank); the next launch vouches for them (replicas_handshake).
+__device__ __forceinline__ void walker_result(const WalkerArgs& A, const Replicas& R, int w, double lnp) {
+    if (A.lnprob) A.lnprob[w] = lnp;
+    if (R.n > 0) {
+        // (this rank's own vector is read by later launches on this device: a plain store; the peers' get system-scope stores)
+        for (int r = 0; r < R.n; ++r) {
+            if (r == R.me) R.lp[r][w] = lnp;
+            else __hip_atomic_store(R.lp[r] + w, lnp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // grid = W workgroups, block = 64 x ntiles threads (ntiles <= 16): wave t owns tile t of the walker and
 // runs tile_work exactly as a single-wave tile_kernel workgroup would (own LDS block, no barrier with
 // its siblings), so per-tile results -- and, with the same summation order, lnprob -- are bit-identical to
@@ -1718,6 +1732,9 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         }
     } else {
         thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
+        // direct-write gather (vp_gather_*): the batch before this one has arrived here from every rank before this one
+        // computes -- the dependency of an ensemble step on the whole ensemble's lnprob, as a blocking all-gather states it
+        if (S.rep.n > 0) replicas_handshake(S.rep);
     }
 #ifdef VP_STAMPS
     VP_STAMP(8);
@@ -1761,7 +1778,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
 #endif
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
     if (oobw && !SAMPLER) {
-        if (tid == 0) A.lnprob[w] = -__builtin_inf();
+        if (tid == 0) walker_result(A, S.rep, w, -__builtin_inf());
         return;
     }
     double total = 0.0;
@@ -1790,7 +1807,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     }
     const double lnp = oobw ? -__builtin_inf() : 0.0 + total;      // lp + lnlike (vfit_mcmc.py:353)
     if (!SAMPLER) {
-        if (lane == 0) A.lnprob[w] = lnp;
+        if (lane == 0) walker_result(A, S.rep, w, lnp);
         return;
     }
     // ---- sampler form: accept / reject by wave 0 (stretch_accept's arithmetic), the walker's chain entry --------

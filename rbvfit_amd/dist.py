@@ -103,6 +103,121 @@ class DeviceShardedPosterior:
         return self.gathered
 
 
+class _DevicePointer:
+    """A raw device allocation as torch can view it (``torch.as_tensor`` reads ``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+class DirectGather:
+    """The per-pass exchange of a walker-sharded ensemble WITHOUT a collective launch (``vp_gather_*``): every rank owns a
+    (world, W) vector that its peers map through IPC handles; ``step()`` is one ``walker_kernel`` launch that writes this
+    rank's lnprob block into every rank's vector and publishes it, and the next ``step()``'s workgroups wait on the device
+    for their peers' previous blocks -- the dependency of a blocking all-gather (an ensemble step needs the whole ensemble's
+    lnprob) at the cost of 8 bytes per walker and rank of peer stores and one flag per rank.
+
+    The IPC handles travel through ``torch.distributed``'s object all-gather (any backend).  ``DirectGather.probe`` builds
+    one, runs two passes and checks them against ``all_gather_into_tensor``; callers fall back to the collective
+    (``DeviceShardedPosterior``) when it returns None -- batches that do not run as one launch, runtimes without IPC."""
+
+    def __init__(self, engine, theta_block_device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.engine = engine
+        self.theta = theta_block_device
+        self.W = int(theta_block_device.shape[0])
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # every rank takes part in both object all-gathers whatever happens on it, and all ranks fail together: a rank that
+        # left early would leave its peers inside a collective
+        mine, err = None, None
+        try:
+            mine = engine.gather_create(self.W, self.world, self.rank)
+        except Exception as exc:
+            err = exc
+        if self.world > 1:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, mine, group=group)
+            if err is None and all(h is not None for h in handles):
+                try:
+                    engine.gather_connect(b"".join(handles))
+                except Exception as exc:
+                    err = exc
+            elif err is None:
+                err = RuntimeError("a peer could not create its gather buffers")
+            oks = [None] * self.world
+            dist.all_gather_object(oks, err is None, group=group)      # (also: every rank has mapped its peers before anyone writes)
+            if err is None and not all(oks):
+                err = RuntimeError("a peer could not map the gather buffers")
+        if err is not None:
+            raise err
+        ptr, _ = engine.gather_state()
+        self.gathered = torch.as_tensor(_DevicePointer(ptr, self.W * self.world), device=theta_block_device.device)
+        self._torch = torch
+
+    def step(self, stream_ptr: Optional[int] = None):
+        """Enqueue one pass on ``stream_ptr`` (default: torch's current stream, which must not be the default stream)."""
+        if stream_ptr is None:
+            stream_ptr = self._torch.cuda.current_stream().cuda_stream
+        self.engine.lnprob_gather_device(self.theta.data_ptr(), self.W, stream_ptr)
+
+    def wait(self, stream_ptr: Optional[int] = None):
+        """Enqueue the device-side wait for every rank's block of the last pass (what the next ``step`` does by itself)."""
+        if stream_ptr is None:
+            stream_ptr = self._torch.cuda.current_stream().cuda_stream
+        self.engine.gather_wait(stream_ptr)
+
+    def timed_out(self) -> bool:
+        return self.engine.gather_state()[1]
+
+    def close(self):
+        self.gathered = None
+        self.engine.gather_destroy()
+
+    @classmethod
+    def probe(cls, engine, theta_block_device, group=None):
+        """A working DirectGather, or None (with the reason in ``DirectGather.last_reason``): two passes are compared with
+        the collective's result on every rank and the ranks agree on the outcome."""
+        import torch
+        import torch.distributed as dist
+        ok, dg, reason = 1, None, ""
+        try:
+            dg = cls(engine, theta_block_device, group)
+            ref_local = torch.empty(dg.W, dtype=torch.float64, device=theta_block_device.device)
+            s = torch.cuda.current_stream().cuda_stream
+            for _ in range(2):
+                dg.step(s)
+            dg.wait(s)
+            engine.lnprob_device(theta_block_device.data_ptr(), ref_local.data_ptr(), dg.W, s)
+            if dg.world > 1:
+                ref = torch.empty(dg.W * dg.world, dtype=torch.float64, device=ref_local.device)
+                dist.all_gather_into_tensor(ref, ref_local, group=group)
+            else:
+                ref = ref_local
+            torch.cuda.synchronize()
+            if dg.timed_out():
+                ok, reason = 0, "a device-side wait timed out"
+            elif not torch.equal(torch.nan_to_num(dg.gathered), torch.nan_to_num(ref)):
+                ok, reason = 0, "the gathered vector differs from the collective's"
+        except Exception as exc:                           # no IPC, not a one-launch batch, ...
+            ok, reason = 0, f"{type(exc).__name__}: {exc}"
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=theta_block_device.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0 and ok:
+                ok, reason = 0, "another rank could not set it up"
+        cls.last_reason = reason
+        if not ok:
+            if dg is not None:
+                try:
+                    dg.close()
+                except Exception:
+                    pass
+            return None
+        return dg
+
+
 class PipelinedGather:
     """Chunked, double-buffered, asynchronous all-gather of a rank-local device vector.
 

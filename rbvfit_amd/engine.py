@@ -149,6 +149,40 @@ class Engine:
         self._check(self._lib.vp_lnprob_batch_device(self._ctx, int(W), self.ndim, C.c_void_p(d_theta_ptr),
                                                      C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr)))
 
+    # ---- direct-write gather between the ranks of a multi-process job (vp_gather_*; rbvfit_amd.dist.DirectGather) ----
+    def gather_create(self, W: int, world: int, rank: int) -> bytes:
+        """This rank's (world, W) gathered vector and flags; returns the 128 bytes of IPC handles its peers need."""
+        self._guard()
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.vp_gather_create(self._ctx, int(W), int(world), int(rank), C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def gather_connect(self, handles_all: bytes):
+        """Map the peers' vectors: ``handles_all`` = the ranks' handle blocks concatenated in rank order."""
+        self._guard()
+        buf = C.create_string_buffer(bytes(handles_all), len(handles_all))
+        self._check(self._lib.vp_gather_connect(self._ctx, C.cast(buf, C.c_void_p)))
+
+    def lnprob_gather_device(self, d_theta_ptr: int, W: int, stream_ptr: int = 0):
+        """One pass: this rank's block evaluated and written into every rank's gathered vector by the kernel itself."""
+        self._guard()
+        self._check(self._lib.vp_lnprob_gather_device(self._ctx, int(W), self.ndim, C.c_void_p(d_theta_ptr), C.c_void_p(stream_ptr)))
+
+    def gather_wait(self, stream_ptr: int = 0):
+        self._guard()
+        self._check(self._lib.vp_gather_wait(self._ctx, C.c_void_p(stream_ptr)))
+
+    def gather_state(self):
+        """(device pointer of this rank's gathered vector, whether a device-side wait timed out); synchronises."""
+        self._guard()
+        p, t = C.c_void_p(), C.c_int(0)
+        self._check(self._lib.vp_gather_state(self._ctx, C.byref(p), C.byref(t)))
+        return int(p.value or 0), bool(t.value)
+
+    def gather_destroy(self):
+        self._guard()
+        self._check(self._lib.vp_gather_destroy(self._ctx))
+
     @property
     def stream_handle(self) -> int:
         """hipStream_t of the context's own (non-blocking) stream."""

@@ -1,0 +1,97 @@
+"""Direct-write gather (vp_gather_*, rbvfit_amd.dist.DirectGather): the per-pass exchange of a walker-sharded ensemble
+written by the lnprob launch itself into every rank's gathered vector.  One GPU is enough to exercise the whole mechanism:
+two PROCESSES on device 0 export / map each other's buffers through hipIpc handles (carried by a gloo process group), write
+into them from their kernels and wait for each other's flags on the device."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_single_rank_gather_is_the_plain_pass():
+    torch = pytest.importorskip("torch")
+    from rbvfit_amd.dist import DirectGather
+    from rbvfit_amd.workloads import make_workload
+    wl = make_workload("C1", walkers=96)
+    th = wl.thetas.copy()
+    th[5, 2] = 1e9                                        # an out-of-bounds walker: -inf through the same path
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        d_theta = torch.from_numpy(th).cuda()
+        ref = torch.empty(96, dtype=torch.float64, device="cuda")
+        dg = DirectGather(wl.engine, d_theta)
+        for _ in range(3):
+            dg.step()
+        dg.wait()
+        wl.engine.lnprob_device(d_theta.data_ptr(), ref.data_ptr(), 96, stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert not dg.timed_out()
+        assert torch.equal(dg.gathered, ref) and torch.isinf(ref[5])
+        assert wl.engine.last_launch_kind == "walker"
+        dg.close()
+    # a batch that does not run as one launch has no direct form: the error says so, and probe() returns None
+    wl2 = make_workload("C2", walkers=64)
+    with torch.cuda.stream(stream):
+        d2 = torch.from_numpy(wl2.thetas).cuda()
+        assert DirectGather.probe(wl2.engine, d2) is None and "one walker_kernel launch" in DirectGather.last_reason
+    wl.engine.close(); wl2.engine.close()
+
+
+def _rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from rbvfit_amd.dist import DirectGather
+    from rbvfit_amd.workloads import make_workload
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    W = 64
+    wl = make_workload("C1", walkers=W, walker_seed=1 + rank)      # every rank its own block of walkers
+    stream = torch.cuda.Stream()
+    out = {}
+    with torch.cuda.stream(stream):
+        d_theta = torch.from_numpy(wl.thetas).cuda()
+        local = torch.empty(W, dtype=torch.float64, device="cuda")
+        dg = DirectGather.probe(wl.engine, d_theta)
+        out["reason"] = DirectGather.last_reason
+        if dg is not None:
+            for _ in range(50):                                    # back-to-back passes: each waits for the peer's last block
+                dg.step()
+            dg.wait()
+            wl.engine.lnprob_device(d_theta.data_ptr(), local.data_ptr(), W, stream.cuda_stream)
+            torch.cuda.synchronize()
+            out["timed_out"] = dg.timed_out()
+            out["gathered"] = dg.gathered.cpu().numpy().copy()
+            out["local"] = local.cpu().numpy().copy()
+    dist.barrier()
+    if dg is not None:
+        dg.close()
+    wl.engine.close()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_on_one_gpu_gather_into_each_other():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 777) % 2000
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0]["reason"] == "" and res[1]["reason"] == "", (res[0]["reason"], res[1]["reason"])
+    for r in (0, 1):
+        assert not res[r]["timed_out"]
+        want = np.concatenate([res[0]["local"], res[1]["local"]])
+        np.testing.assert_array_equal(res[r]["gathered"], want)    # every rank holds both blocks, bit for bit
+    assert not np.array_equal(res[0]["local"], res[1]["local"])
