@@ -156,11 +156,13 @@ class DirectGather:
         self.gathered = torch.as_tensor(_DevicePointer(ptr, self.W * self.world), device=theta_block_device.device)
         self._torch = torch
 
-    def step(self, stream_ptr: Optional[int] = None):
-        """Enqueue one pass on ``stream_ptr`` (default: torch's current stream, which must not be the default stream)."""
+    def step(self, stream_ptr: Optional[int] = None, theta=None):
+        """Enqueue one pass on ``stream_ptr`` (default: torch's current stream, which must not be the default stream);
+        ``theta``: another (W, D) device block than the one the object was made with."""
         if stream_ptr is None:
             stream_ptr = self._torch.cuda.current_stream().cuda_stream
-        self.engine.lnprob_gather_device(self.theta.data_ptr(), self.W, stream_ptr)
+        th = self.theta if theta is None else theta
+        self.engine.lnprob_gather_device(th.data_ptr(), self.W, stream_ptr)
 
     def wait(self, stream_ptr: Optional[int] = None):
         """Enqueue the device-side wait for every rank's block of the last pass (what the next ``step`` does by itself)."""
@@ -186,8 +188,12 @@ class DirectGather:
             dg = cls(engine, theta_block_device, group)
             ref_local = torch.empty(dg.W, dtype=torch.float64, device=theta_block_device.device)
             s = torch.cuda.current_stream().cuda_stream
-            for _ in range(2):
-                dg.step(s)
+            # a pass on other values first, read back here, so that a stale copy of the vector anywhere would show below
+            other = theta_block_device.roll(1, dims=0).contiguous()
+            dg.step(s, theta=other)
+            dg.wait(s)
+            stale_bait = float(torch.nan_to_num(dg.gathered).sum().item())
+            dg.step(s)
             dg.wait(s)
             engine.lnprob_device(theta_block_device.data_ptr(), ref_local.data_ptr(), dg.W, s)
             if dg.world > 1:
@@ -199,7 +205,7 @@ class DirectGather:
             if dg.timed_out():
                 ok, reason = 0, "a device-side wait timed out"
             elif not torch.equal(torch.nan_to_num(dg.gathered), torch.nan_to_num(ref)):
-                ok, reason = 0, "the gathered vector differs from the collective's"
+                ok, reason = 0, f"the gathered vector differs from the collective's (sum of the pass before: {stale_bait:.6g})"
         except Exception as exc:                           # no IPC, not a one-launch batch, ...
             ok, reason = 0, f"{type(exc).__name__}: {exc}"
         if dist.is_initialized() and dist.get_world_size(group) > 1:
