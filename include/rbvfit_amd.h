@@ -105,10 +105,10 @@ int vp_lnprob_batch_device(vp_ctx* ctx, int W, int D, const double* d_theta, dou
  * 408-440: every worker's results return to the sampler): each rank owns a (world, W) vector of device memory that its peers
  * map (hipIpc handles, carried by the job's own channel -- rbvfit_amd.dist.DirectGather uses torch.distributed's object
  * all-gather).  vp_lnprob_gather_device is vp_lnprob_batch_device with the output written by the kernel itself into this rank's
- * block of EVERY rank's vector (8 bytes per walker and rank) and published by the launch's last workgroup; the next pass's
- * workgroups start by waiting, on the device, for their peers' blocks of the pass before -- the dependency a blocking all-gather
- * states, without a collective launch or a host wait.  Only batches that run as ONE walker_kernel launch (VP_ESTATE otherwise:
- * use vp_lnprob_batch_device and the collective).
+ * block of EVERY rank's vector (8 bytes per walker and rank); the next pass's first launch raises this rank's flag in every
+ * peer and waits, on the device, for its peers' flags of the pass before -- the dependency a blocking all-gather
+ * states, without a collective launch or a host wait.  (Batches that take several launches: the first one handshakes, the final
+ * reduction writes into the vectors.)
  *   vp_gather_create    allocates this rank's vector and flags; handles_out: 2 x 64 bytes (hipIpcMemHandle_t of both), zeros
  *                       when world == 1.  1 <= world <= 8.
  *   vp_gather_connect   handles_all: world x 2 x 64 bytes, rank-major (this rank's own entry is not opened).

@@ -164,6 +164,7 @@ struct vp_ctx {
         double* peer_buf[vp::MAX_REPLICAS] = {};
         int* peer_flags[vp::MAX_REPLICAS] = {};
     } gather;
+    const vp::Replicas* gather_rep = nullptr;   // set around an enqueue_lnprob whose results go into the ranks' gathered vectors
     // model_flux / voigt_h scratch
     double* d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -357,8 +358,10 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
         g.nb_cl = (W + g.cl_wpw - 1) / g.cl_wpw;
     }
     g.nb_flag = do_flags ? W : 0;
+    // (direct-write gather: the pass's first launch -- the one that applies the box prior -- handshakes with the peers)
+    const vp::Replicas rep = (c->gather_rep && do_flags) ? *c->gather_rep : vp::Replicas{};
     hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(g.nb_line + g.nb_cl + g.nb_flag), dim3(64), 0, s, d_theta, W, c->D,
-                       in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g);
+                       in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g, rep);
 }
 
 // walker_kernel: the whole batch in ONE launch (workgroup = walker, wave = tile).  Possible for a single
@@ -480,7 +483,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     const int Wp = c->policy_W > 0 ? c->policy_W : W;       // rows the launch structure is chosen for
     if (walker_applies(c, Wp)) {
         c->last_kind = 1;
-        launch_walker(c, W, d_theta, d_out, s);
+        launch_walker(c, W, d_theta, d_out, s, c->gather_rep);
         if (prof) {
             size_t m1 = prof_mark(c, s);
             c->spans.push_back({m0, m1, 1});
@@ -502,7 +505,9 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     // walkers 26.5 / 26.7, 512: 32.3 / 33.0-33.9, 2048: 88.9 / 92.5, 8192: 314 / 329.
     int fmode = ((long)Wp * c->total_tiles_g[0] < 6144) ? 1 : 0;
     if (c->tune.finalize >= 0) fmode = c->tune.finalize ? 1 : 0;      // 0: own launch, 1: ticket
+    if (c->gather_rep) fmode = 0;                    // (the finalize launch is what writes into the ranks' gathered vectors)
     const bool fused = fmode != 0;
+    const vp::Replicas frep = c->gather_rep ? *c->gather_rep : vp::Replicas{};
     const vp::FinalizeArgs fin{c->d_ticket, c->d_tile_off + sel * (c->inst.size() + 1), c->d_sum_logw,
                                d_out, (int)c->inst.size(), ntot, fmode};
     // ---- several instruments with one set of records, small batch: all their tiles in ONE launch (tile_kernel_multi)
@@ -543,6 +548,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             //  end of every wave cost more -- C3 at 64 walkers 56.9 us by ticket, 47.6 by launch; scripts/structure_check.py)
             int fm = 0;
             if (c->tune.finalize >= 0) fm = c->tune.finalize ? 1 : 0;
+            if (c->gather_rep) fm = 0;
             const vp::FinalizeArgs fw{c->d_ticket, c->d_tile_off + 2 * (ni + 1), c->d_sum_logw, d_out, (int)ni, nt, fm};
             const dim3 grid(W, nt), block(64);
             if (in0.dev.method == VP_VOIGT_FAST)
@@ -554,7 +560,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
                 bv.n_inst = (int)ni;
                 for (size_t k = 0; k < ni; ++k) { bv.tile_off[k] = tb.off[k]; bv.sum_logw[k] = c->inst[k].sum_logw; }
                 bv.tile_off[ni] = nt;
-                hipLaunchKernelGGL((vp::finalize_kernel<true>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, nt, W, c->d_flags, fw, bv);
+                hipLaunchKernelGGL((vp::finalize_kernel<true>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, nt, W, c->d_flags, fw, bv, frep);
             }
             HIP_TRY(c, hipGetLastError());
             return VP_OK;
@@ -613,9 +619,9 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
                 bv.sum_logw[k] = c->inst[k].sum_logw;
             }
             bv.tile_off[ni] = off;
-            hipLaunchKernelGGL((vp::finalize_kernel<true>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, ntot, W, c->d_flags, fin, bv);
+            hipLaunchKernelGGL((vp::finalize_kernel<true>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, ntot, W, c->d_flags, fin, bv, frep);
         } else {
-            hipLaunchKernelGGL((vp::finalize_kernel<false>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, ntot, W, c->d_flags, fin, bv);
+            hipLaunchKernelGGL((vp::finalize_kernel<false>), dim3((W + 63) / 64), dim3(64), 0, s, c->d_partial, ntot, W, c->d_flags, fin, bv, frep);
         }
         if (prof) {
             size_t m3 = prof_mark(c, s);
@@ -1168,14 +1174,12 @@ int vp_lnprob_gather_device(vp_ctx* c, int W, int D, const double* d_theta, void
     if (W != G.W) return fail(c, VP_EINVAL, "vp_lnprob_gather_device: W differs from the gather's block size");
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
-    if (!walker_applies(c, c->policy_W > 0 ? c->policy_W : W))
-        return fail(c, VP_ESTATE, "vp_lnprob_gather_device: this batch does not run as one walker_kernel launch (use vp_lnprob_batch_device and a collective)");
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const vp::Replicas R = gather_replicas(c, ++G.seq);
-    c->last_kind = 1;
-    launch_walker(c, W, d_theta, nullptr, s, &R);
-    HIP_TRY(c, hipGetLastError());
-    return VP_OK;
+    c->gather_rep = &R;
+    rc = enqueue_lnprob(c, W, d_theta, nullptr, s);
+    c->gather_rep = nullptr;
+    return rc;
 }
 
 int vp_gather_wait(vp_ctx* c, void* hip_stream) {

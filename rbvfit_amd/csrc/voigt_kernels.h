@@ -369,7 +369,9 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
                                                         const double* __restrict__ ub,
                                                         double* __restrict__ lc, int* __restrict__ flags,
                                                         int do_flags, double* __restrict__ lnprob_out,
-                                                        int* __restrict__ genflag, PrepGrid G) {
+                                                        int* __restrict__ genflag, PrepGrid G, Replicas R) {
+    // direct-write gather (vp_gather_*): the batch before this one has arrived here from every rank before this one starts
+    if (R.n > 1) replicas_handshake(R);
     const int nrec = T.L + T.NCm;                     // records per walker: lines, then clusters
     const int lane = threadIdx.x;
     int blk = blockIdx.x;
@@ -1868,7 +1870,7 @@ struct FinalizeByValue {           // the per-instrument tables in the kernel ar
 };
 template <bool BYVALUE>
 __global__ __launch_bounds__(64) void finalize_kernel(double* __restrict__ partial, int stride, int W,
-                                                      const int* __restrict__ flags, FinalizeArgs F, FinalizeByValue V) {
+                                                      const int* __restrict__ flags, FinalizeArgs F, FinalizeByValue V, Replicas R) {
     const int w = blockIdx.x * 64 + threadIdx.x;
     if (w >= W) return;
     double* __restrict__ row = partial + (size_t)w * stride;
@@ -1889,8 +1891,14 @@ __global__ __launch_bounds__(64) void finalize_kernel(double* __restrict__ parti
         for (; tt < t1; ++tt) sk += row[tt];
         total += -0.5 * (sk - (BYVALUE ? V.sum_logw[k] : F.sum_logw[k]));   // vfit_mcmc.py:309-311
     }
-    if (oob) return;                                  // out-of-bounds walkers keep the -inf written by prep
-    F.lnprob[w] = 0.0 + total;                           // lp + lnlike (vfit_mcmc.py:353)
+    const double lnp = oob ? -__builtin_inf() : 0.0 + total;     // lp + lnlike (vfit_mcmc.py:353)
+    if (F.lnprob && !oob) F.lnprob[w] = lnp;          // (out-of-bounds walkers keep the -inf written by prep)
+    if (R.n > 0) {                                    // direct-write gather: this rank's block of every rank's vector
+        for (int r = 0; r < R.n; ++r) {
+            if (r == R.me) R.lp[r][w] = lnp;
+            else __hip_atomic_store(R.lp[r] + w, lnp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // Test hook: H(a_i, x_j) with the production tier logic (wave = 64 consecutive x_j of one a_i).

@@ -112,14 +112,14 @@ class _DevicePointer:
 
 class DirectGather:
     """The per-pass exchange of a walker-sharded ensemble WITHOUT a collective launch (``vp_gather_*``): every rank owns a
-    (world, W) vector that its peers map through IPC handles; ``step()`` is one ``walker_kernel`` launch that writes this
-    rank's lnprob block into every rank's vector and publishes it, and the next ``step()``'s workgroups wait on the device
-    for their peers' previous blocks -- the dependency of a blocking all-gather (an ensemble step needs the whole ensemble's
-    lnprob) at the cost of 8 bytes per walker and rank of peer stores and one flag per rank.
+    (world, W) vector that its peers map through IPC handles; ``step()`` is the pass's own launches, the last of which writes
+    this rank's lnprob block into every rank's vector, and the next ``step()``'s first launch raises this rank's flag in every
+    peer and waits on the device for its peers' -- the dependency of a blocking all-gather (an ensemble step needs the whole
+    ensemble's lnprob) at the cost of 8 bytes per walker and rank of peer stores and one flag per rank.
 
     The IPC handles travel through ``torch.distributed``'s object all-gather (any backend).  ``DirectGather.probe`` builds
     one, runs two passes and checks them against ``all_gather_into_tensor``; callers fall back to the collective
-    (``DeviceShardedPosterior``) when it returns None -- batches that do not run as one launch, runtimes without IPC."""
+    (``DeviceShardedPosterior``) when it returns None -- runtimes without IPC between the ranks' devices."""
 
     def __init__(self, engine, theta_block_device, group=None):
         import torch

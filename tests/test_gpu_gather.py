@@ -33,15 +33,28 @@ def test_single_rank_gather_is_the_plain_pass():
         assert torch.equal(dg.gathered, ref) and torch.isinf(ref[5])
         assert wl.engine.last_launch_kind == "walker"
         dg.close()
-    # a batch that does not run as one launch has no direct form: the error says so, and probe() returns None
+    # a batch that takes several launches (records, far-field expansions, tiles, final reduction): the first one handshakes,
+    # the last one writes into the gathered vectors
     wl2 = make_workload("C2", walkers=64)
+    th2 = wl2.thetas.copy()
+    th2[7, 0] = -1e9
     with torch.cuda.stream(stream):
-        d2 = torch.from_numpy(wl2.thetas).cuda()
-        assert DirectGather.probe(wl2.engine, d2) is None and "one walker_kernel launch" in DirectGather.last_reason
+        d2 = torch.from_numpy(th2).cuda()
+        ref2 = torch.empty(64, dtype=torch.float64, device="cuda")
+        dg2 = DirectGather.probe(wl2.engine, d2)
+        assert dg2 is not None, DirectGather.last_reason
+        for _ in range(3):
+            dg2.step()
+        dg2.wait()
+        assert wl2.engine.last_launch_kind.startswith("tiles")
+        wl2.engine.lnprob_device(d2.data_ptr(), ref2.data_ptr(), 64, stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(dg2.gathered, ref2) and torch.isinf(ref2[7]) and not dg2.timed_out()
+        dg2.close()
     wl.engine.close(); wl2.engine.close()
 
 
-def _rank(rank, world, port, q):
+def _rank(rank, world, port, q, config="C1"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
@@ -51,7 +64,7 @@ def _rank(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     W = 64
-    wl = make_workload("C1", walkers=W, walker_seed=1 + rank)      # every rank its own block of walkers
+    wl = make_workload(config, walkers=W, walker_seed=1 + rank)    # every rank its own block of walkers
     stream = torch.cuda.Stream()
     out = {}
     with torch.cuda.stream(stream):
@@ -77,12 +90,13 @@ def _rank(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_processes_on_one_gpu_gather_into_each_other():
+@pytest.mark.parametrize("config", ["C1", "C2"])         # one launch per pass / several launches per pass
+def test_two_processes_on_one_gpu_gather_into_each_other(config):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + 777) % 2000
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 777 + (13 if config == "C2" else 0)) % 2000
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, q, config)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=500) for _ in procs)
