@@ -111,12 +111,15 @@ int vp_lnprob_batch_device(vp_ctx* ctx, int W, int D, const double* d_theta, dou
  * reduction writes into the vectors.)
  *   vp_gather_create    allocates this rank's vector and flags; handles_out: 2 x 64 bytes (hipIpcMemHandle_t of both), zeros
  *                       when world == 1.  1 <= world <= 8.
- *   vp_gather_connect   handles_all: world x 2 x 64 bytes, rank-major (this rank's own entry is not opened).
+ *   vp_gather_connect   handles_all: world x 2 x 64 bytes, rank-major (this rank's own entry is not opened).  shared_device != 0:
+ *                       some ranks share a GPU -- a launch that waits for its peers inside its workgroups needs their launches
+ *                       to start while it holds its wave slots, which one GPU cannot promise to several ranks; the handshake is
+ *                       then a one-wave launch of its own in front of every pass.
  *   vp_gather_wait      enqueues a one-wave kernel that returns once every rank's block of the LAST pass has landed here.
  *   vp_gather_state     the device pointer of this rank's (world, W) vector; *timed_out != 0 if a device-side wait gave up
  *                       (~ a second of polling: a peer that never ran), synchronises.  Either pointer may be NULL. */
 int vp_gather_create(vp_ctx* ctx, int W, int world, int rank, void* handles_out);
-int vp_gather_connect(vp_ctx* ctx, const void* handles_all);
+int vp_gather_connect(vp_ctx* ctx, const void* handles_all, int shared_device);
 int vp_lnprob_gather_device(vp_ctx* ctx, int W, int D, const double* d_theta, void* hip_stream);
 int vp_gather_wait(vp_ctx* ctx, void* hip_stream);
 int vp_gather_state(vp_ctx* ctx, double** d_gathered, int* timed_out);

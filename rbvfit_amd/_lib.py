@@ -45,7 +45,7 @@ SIGNATURES = {
     "vp_lnprob_batch": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp]),
     "vp_lnprob_batch_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vp_gather_create": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "vp_gather_connect": (C.c_int, [_ctx, C.c_void_p]),
+    "vp_gather_connect": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "vp_lnprob_gather_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vp_gather_wait": (C.c_int, [_ctx, C.c_void_p]),
     "vp_gather_state": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),

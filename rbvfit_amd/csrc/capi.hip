@@ -158,6 +158,7 @@ struct vp_ctx {
     struct Gather {
         int W = 0, world = 0, rank = 0, seq = 0;
         bool connected = false, finegrained = false;
+        bool shared_device = false;            // some ranks share a GPU: the handshake is a launch of its own (replicas_handshake)
         double* buf = nullptr;                 // (world, W) this rank's gathered vector
         int* flags = nullptr;                  // (MAX_REPLICAS) flags[r] = the last pass whose block from rank r has landed here
         unsigned int* done = nullptr;          // workgroup counters of the running launch (PUB_GROUPS + 1) | timeout flag (int)
@@ -1138,11 +1139,12 @@ int vp_gather_create(vp_ctx* c, int W, int world, int rank, void* handles_out) {
     return VP_OK;
 }
 
-int vp_gather_connect(vp_ctx* c, const void* handles_all) {
+int vp_gather_connect(vp_ctx* c, const void* handles_all, int shared_device) {
     if (!c) return VP_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
     vp_ctx::Gather& G = c->gather;
     if (!G.buf) return fail(c, VP_ESTATE, "vp_gather_connect: call vp_gather_create first");
+    G.shared_device = shared_device != 0;
     if (G.connected) return VP_OK;
     if (!handles_all) return fail(c, VP_EINVAL, "vp_gather_connect: NULL handles");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1175,7 +1177,11 @@ int vp_lnprob_gather_device(vp_ctx* c, int W, int D, const double* d_theta, void
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    const vp::Replicas R = gather_replicas(c, ++G.seq);
+    vp::Replicas R = gather_replicas(c, ++G.seq);
+    if (G.shared_device && G.world > 1) {            // the handshake as a one-wave launch in front of the pass
+        hipLaunchKernelGGL(gather_wait_kernel, dim3(1), dim3(64), 0, s, R);
+        R.sync = 0;
+    }
     c->gather_rep = &R;
     rc = enqueue_lnprob(c, W, d_theta, nullptr, s);
     c->gather_rep = nullptr;

@@ -202,9 +202,12 @@ __device__ __forceinline__ void replicas_publish(const Replicas& R, unsigned int
 // workgroups, no fence, nothing at the end of a launch: a count (a returning device-scope atomic or two per workgroup behind its
 // last store) cost the tail of a 512-workgroup launch 5.5 us, release fences in front of it -- L2 write-backs on a GPU of eight
 // L2s -- 11 us; a blocking RCCL all_gather 9 us.
+// A launch that waits inside its workgroups needs its peers' launches to START while it holds its wave slots: true for one
+// rank per GPU; ranks that share a GPU (tests, small jobs) could fill it with waiting workgroups, so for them the handshake is
+// a one-wave launch of its own in front of the pass (R.sync = 0 in the pass's launches; vp_gather_connect's `shared_device`).
 // all lanes of every wave; R.seq = the pass this launch computes (the flags of pass R.seq - 1 are raised and awaited)
 __device__ __forceinline__ void replicas_handshake(const Replicas& R) {
-    if (R.seq <= 1 || R.n <= 1) return;
+    if (R.seq <= 1 || R.n <= 1 || !R.sync) return;
     const int lane = threadIdx.x & 63;
     const int need = R.seq - 1;
     if (blockIdx.x == 0 && threadIdx.x < 64 && lane < R.n && lane != R.me)

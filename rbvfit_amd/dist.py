@@ -19,6 +19,8 @@ and overlaps step k+1's kernels; nothing on a rank's critical path waits for a p
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -129,6 +131,7 @@ class DirectGather:
         self.W = int(theta_block_device.shape[0])
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.shared_device = False
         # every rank takes part in both object all-gathers whatever happens on it, and all ranks fail together: a rank that
         # left early would leave its peers inside a collective
         mine, err = None, None
@@ -138,10 +141,14 @@ class DirectGather:
             err = exc
         if self.world > 1:
             handles = [None] * self.world
-            dist.all_gather_object(handles, mine, group=group)
+            dist.all_gather_object(handles, (mine, engine.device_identity), group=group)
+            ids = [h[1] for h in handles]
+            handles = [h[0] for h in handles]
+            # ranks that share a GPU cannot wait for each other inside full-size launches (vp_gather_connect)
+            self.shared_device = len(set(ids)) < len(ids) and os.environ.get("RBVFIT_AMD_GATHER_INKERNEL") != "1"
             if err is None and all(h is not None for h in handles):
                 try:
-                    engine.gather_connect(b"".join(handles))
+                    engine.gather_connect(b"".join(handles), self.shared_device)
                 except Exception as exc:
                     err = exc
             elif err is None:

@@ -157,11 +157,24 @@ class Engine:
         self._check(self._lib.vp_gather_create(self._ctx, int(W), int(world), int(rank), C.cast(buf, C.c_void_p)))
         return buf.raw
 
-    def gather_connect(self, handles_all: bytes):
-        """Map the peers' vectors: ``handles_all`` = the ranks' handle blocks concatenated in rank order."""
+    def gather_connect(self, handles_all: bytes, shared_device: bool = False):
+        """Map the peers' vectors: ``handles_all`` = the ranks' handle blocks concatenated in rank order; ``shared_device``:
+        some ranks share a GPU (the handshake is then a launch of its own in front of every pass)."""
         self._guard()
         buf = C.create_string_buffer(bytes(handles_all), len(handles_all))
-        self._check(self._lib.vp_gather_connect(self._ctx, C.cast(buf, C.c_void_p)))
+        self._check(self._lib.vp_gather_connect(self._ctx, C.cast(buf, C.c_void_p), int(bool(shared_device))))
+
+    @property
+    def device_identity(self) -> str:
+        """Host name and PCI bus id of the context's GPU: what tells ranks apart that share a device."""
+        import socket
+        import torch
+        try:
+            props = torch.cuda.get_device_properties(self.device_id)
+            tag = getattr(props, "uuid", None) or f"{getattr(props, 'pci_bus_id', '')}:{getattr(props, 'pci_device_id', '')}:{self.device_id}"
+        except Exception:
+            tag = str(self.device_id)
+        return f"{socket.gethostname()}/{tag}"
 
     def lnprob_gather_device(self, d_theta_ptr: int, W: int, stream_ptr: int = 0):
         """One pass: this rank's block evaluated and written into every rank's gathered vector by the kernel itself."""

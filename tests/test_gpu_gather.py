@@ -54,9 +54,11 @@ def test_single_rank_gather_is_the_plain_pass():
     wl.engine.close(); wl2.engine.close()
 
 
-def _rank(rank, world, port, q, config="C1"):
+def _rank(rank, world, port, q, config="C1", inkernel=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if inkernel:
+        os.environ["RBVFIT_AMD_GATHER_INKERNEL"] = "1"     # (small batches: both ranks' launches fit on the GPU together)
     import torch
     import torch.distributed as dist
     from rbvfit_amd.dist import DirectGather
@@ -72,6 +74,7 @@ def _rank(rank, world, port, q, config="C1"):
         local = torch.empty(W, dtype=torch.float64, device="cuda")
         dg = DirectGather.probe(wl.engine, d_theta)
         out["reason"] = DirectGather.last_reason
+        out["shared"] = dg.shared_device if dg is not None else None
         if dg is not None:
             for _ in range(50):                                    # back-to-back passes: each waits for the peer's last block
                 dg.step()
@@ -90,13 +93,15 @@ def _rank(rank, world, port, q, config="C1"):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("config", ["C1", "C2"])         # one launch per pass / several launches per pass
-def test_two_processes_on_one_gpu_gather_into_each_other(config):
+@pytest.mark.parametrize("config,inkernel", [("C1", False), ("C1", True), ("C2", False), ("C2", True)])
+def test_two_processes_on_one_gpu_gather_into_each_other(config, inkernel):
+    """config: one launch per pass / several; inkernel: the handshake inside the pass's first launch (what ranks on GPUs of their
+    own get) or -- ranks that share a GPU are told apart by their device identity -- a one-wave launch in front of it."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + 777 + (13 if config == "C2" else 0)) % 2000
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q, config)) for r in range(2)]
+    port = 29500 + (os.getpid() + 777 + (13 if config == "C2" else 0) + (29 if inkernel else 0)) % 2000
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, q, config, inkernel)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=500) for _ in procs)
@@ -105,6 +110,7 @@ def test_two_processes_on_one_gpu_gather_into_each_other(config):
         assert p.exitcode == 0
     assert res[0]["reason"] == "" and res[1]["reason"] == "", (res[0]["reason"], res[1]["reason"])
     for r in (0, 1):
+        assert res[r]["shared"] == (not inkernel)
         assert not res[r]["timed_out"]
         want = np.concatenate([res[0]["local"], res[1]["local"]])
         np.testing.assert_array_equal(res[r]["gathered"], want)    # every rank holds both blocks, bit for bit
