@@ -54,6 +54,32 @@ def test_single_rank_gather_is_the_plain_pass():
     wl.engine.close(); wl2.engine.close()
 
 
+def test_gather_argument_and_state_errors():
+    torch = pytest.importorskip("torch")
+    from rbvfit_amd.workloads import make_workload
+    wl = make_workload("C1", walkers=32)
+    eng = wl.engine
+    d_theta = torch.from_numpy(wl.thetas).cuda()
+    with pytest.raises(RuntimeError, match="no connected gather"):
+        eng.lnprob_gather_device(d_theta.data_ptr(), 32, 0)
+    with pytest.raises(RuntimeError, match="world"):
+        eng.gather_create(32, 9, 0)                       # more ranks than a vector has flags for
+    with pytest.raises(RuntimeError, match="rank"):
+        eng.gather_create(32, 2, 2)
+    eng.gather_create(32, 2, 0)                           # two ranks: usable only once the peer's handles are mapped
+    with pytest.raises(RuntimeError, match="no connected gather"):
+        eng.lnprob_gather_device(d_theta.data_ptr(), 32, 0)
+    eng.gather_destroy()
+    eng.gather_create(32, 1, 0)
+    with pytest.raises(RuntimeError, match="block size"):
+        eng.lnprob_gather_device(d_theta.data_ptr(), 16, 0)
+    eng.lnprob_gather_device(d_theta.data_ptr(), 32, 0)
+    ptr, timed_out = eng.gather_state()
+    assert ptr != 0 and not timed_out
+    eng.gather_destroy()
+    eng.close()
+
+
 def _rank(rank, world, port, q, config="C1", inkernel=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
