@@ -137,7 +137,7 @@ struct vp_ctx {
     int* d_flags = nullptr;      // (capW)
     unsigned int* d_ticket = nullptr;  // (capW) arrival counters of the fused final reduction
     int* d_genflag = nullptr;    // (capW) walkers with lines outside the fast domain (per instrument pass)
-    double* d_ff = nullptr;      // (capW, cap_ffblk, FF_STRIDE) far-field expansions of the instrument being evaluated
+    double* d_ff = nullptr;      // (capW x cap_ffblk, FF_STRIDE) far-field expansions, instrument after instrument
     int cap_ffblk = 0;
     std::vector<double> h_lb;    // host copy of the lower bounds
     std::vector<double> h_ub;    // ... and of the upper bounds
@@ -268,7 +268,7 @@ int ensure_workspace(vp_ctx* c, int W) {
     }
     int ffblk = 0;
     for (auto& in : c->inst)
-        if (in.ff_on) ffblk = std::max({ffblk, in.dev.ntiles * in.dev.ff_nblk, in.dev_s.ntiles * in.dev_s.ff_nblk});
+        if (in.ff_on) ffblk += std::max(in.dev.ntiles * in.dev.ff_nblk, in.dev_s.ntiles * in.dev_s.ff_nblk);   // (every instrument its own stretch)
     if (W <= c->capW && maxL <= c->capL && c->total_tiles <= c->cap_tiles && ffblk <= c->cap_ffblk) return VP_OK;
     // a stream-ordered previous call may still be using the old buffers
     HIP_TRY(c, hipDeviceSynchronize());
@@ -567,6 +567,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             return VP_OK;
         }
     }
+    bool ff_made = false;                            // this instrument's expansions came with the previous one's launch
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
@@ -584,16 +585,40 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         // when the instrument is added); the crossover sits near 2e5 covered (walker, block, item) triples: C2 at 256
         // walkers (0.195e6) 72.7 / 71.5 us, the 40-line FeII fit at 1024 walkers (0.17e6) 164.9 / 161.1, the 20-line one
         // at 1024 (0.09e6) 90.4 / 93.2.
-        const bool ff_pays = c->tune.farfield > 0 || in.ff_cover * (double)Wp * geom.ntiles * geom.ff_nblk * in.ff_items >= 2.0e5;
-        double* ff = (in.ff_on && c->d_ff && ff_pays) ? c->d_ff : nullptr;
-        if (ff) {                                        // the blocks' far-field expansions from the records just made
+        auto ff_wanted = [&](const Instrument& x) {
+            const vp::InstDev& gx = sel ? x.dev_s : x.dev;
+            const bool pays = c->tune.farfield > 0 || x.ff_cover * (double)Wp * gx.ntiles * gx.ff_nblk * x.ff_items >= 2.0e5;
+            return x.ff_on && c->d_ff && pays;
+        };
+        // every instrument's expansions have their own stretch of the workspace (W x its blocks), in instrument order
+        size_t ff_off = 0;
+        for (size_t i = 0; i < k; ++i) {
+            const vp::InstDev& gi = sel ? c->inst[i].dev_s : c->inst[i].dev;
+            if (c->inst[i].ff_on) ff_off += (size_t)W * gi.ntiles * gi.ff_nblk * vp::FF_STRIDE;
+        }
+        double* ff = ff_wanted(in) ? c->d_ff + ff_off : nullptr;
+        if (ff && !ff_made) {                            // the blocks' far-field expansions from the records just made
             c->last_kind = 2;
             vp::InstDev g2 = geom;
             g2.ff = ff;
             const int nbk = geom.ntiles * geom.ff_nblk;
             const size_t ffl = vp::farfield_lds_bytes(in.lines.L, in.lines.NCm);
-            if (g2.ff_members) hipLaunchKernelGGL((vp::farfield_kernel<9, true>), dim3((nbk + 63) / 64, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, in.lines, c->d_lc, W);
-            else hipLaunchKernelGGL((vp::farfield_kernel<6, false>), dim3((nbk + 63) / 64, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, in.lines, c->d_lc, W);
+            // the next instrument's too, in the same launch, when it has these line tables (the same records)
+            const Instrument* nx = (k + 1 < c->inst.size() && !prof) ? &c->inst[k + 1] : nullptr;
+            if (nx && nx->same_lines_as_prev && !c->tune.no_shared_prep && ff_wanted(*nx) && (sel ? nx->dev_s : nx->dev).ff_members == g2.ff_members) {
+                vp::InstDev g3 = sel ? nx->dev_s : nx->dev;
+                g3.ff = ff + (size_t)W * nbk * vp::FF_STRIDE;
+                const int nbk1 = g3.ntiles * g3.ff_nblk, nbx0 = (nbk + 63) / 64, nbx1 = (nbk1 + 63) / 64;
+                if (g2.ff_members) hipLaunchKernelGGL((vp::farfield_kernel2<9, true>), dim3(nbx0 + nbx1, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, g3, nbx0, in.lines, c->d_lc, W);
+                else hipLaunchKernelGGL((vp::farfield_kernel2<6, false>), dim3(nbx0 + nbx1, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, g3, nbx0, in.lines, c->d_lc, W);
+                ff_made = true;                          // (consumed by the next instrument's pass of this loop)
+            } else {
+                if (g2.ff_members) hipLaunchKernelGGL((vp::farfield_kernel<9, true>), dim3((nbk + 63) / 64, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, in.lines, c->d_lc, W);
+                else hipLaunchKernelGGL((vp::farfield_kernel<6, false>), dim3((nbk + 63) / 64, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, in.lines, c->d_lc, W);
+            }
+        } else if (ff) {
+            c->last_kind = 2;
+            ff_made = false;
         }
         size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin,

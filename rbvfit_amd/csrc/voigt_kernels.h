@@ -594,7 +594,7 @@ __host__ __device__ inline size_t farfield_lds_bytes(int L, int NCm) {
 }
 
 template <int M, bool MEMBERS>      // MEMBERS: cluster members may be taken line by line (InstDev::ff_members); the plain instance is free of it
-__global__ __launch_bounds__(64 * FF_WAVES) void farfield_kernel(InstDev I, LinesDev T, const double* __restrict__ lc, int W) {
+__device__ __forceinline__ void farfield_body(const InstDev& I, const LinesDev& T, const double* __restrict__ lc, int W, int bx) {
     constexpr double XMIN = M >= 9 ? 14.0 : 30.0;
     extern __shared__ double ffs[];
     // one workgroup = 64 blocks of ONE walker (grid.y), lane = block: the walker's records, the cluster tables and all
@@ -602,8 +602,8 @@ __global__ __launch_bounds__(64 * FF_WAVES) void farfield_kernel(InstDev I, Line
     const int nb = I.ntiles * I.ff_nblk;
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = min((int)(blockIdx.x * 64 + lane), nb - 1);
-    const bool store = (int)(blockIdx.x * 64 + lane) < nb;     // (lanes past the end repeat the last block)
+    const int b = min(bx * 64 + lane, nb - 1);
+    const bool store = bx * 64 + lane < nb;                     // (lanes past the end repeat the last block)
     const long idx = (long)w * nb + b;
     double* __restrict__ out = I.ff + (size_t)idx * FF_STRIDE;
     const double gc = I.ff_tab[4 * b], hw = I.ff_tab[4 * b + 1];
@@ -750,6 +750,17 @@ __global__ __launch_bounds__(64 * FF_WAVES) void farfield_kernel(InstDev I, Line
     for (int j = 0; j < FF_NC; ++j) out[j] = c[j];
     reinterpret_cast<unsigned long long*>(out)[FF_MASK0] = mask[0];
     reinterpret_cast<unsigned long long*>(out)[FF_MASK0 + 1] = mask[1];
+}
+template <int M, bool MEMBERS>
+__global__ __launch_bounds__(64 * FF_WAVES) void farfield_kernel(InstDev I, LinesDev T, const double* __restrict__ lc, int W) {
+    farfield_body<M, MEMBERS>(I, T, lc, W, (int)blockIdx.x);
+}
+// Two instruments of a joint fit that share their records (same line tables): the blocks of both in ONE launch
+// (grid.x = nbx0 + nbx1 waves of blocks; C3: two launches of 22 us that each leave the GPU half empty).
+template <int M, bool MEMBERS>
+__global__ __launch_bounds__(64 * FF_WAVES) void farfield_kernel2(InstDev I0, InstDev I1, int nbx0, LinesDev T, const double* __restrict__ lc, int W) {
+    if ((int)blockIdx.x < nbx0) farfield_body<M, MEMBERS>(I0, T, lc, W, (int)blockIdx.x);
+    else farfield_body<M, MEMBERS>(I1, T, lc, W, (int)blockIdx.x - nbx0);
 }
 
 // ---------------------------------------------------------------------------------------------
