@@ -585,10 +585,28 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         // when the instrument is added); the crossover sits near 2e5 covered (walker, block, item) triples: C2 at 256
         // walkers (0.195e6) 72.7 / 71.5 us, the 40-line FeII fit at 1024 walkers (0.17e6) 164.9 / 161.1, the 20-line one
         // at 1024 (0.09e6) 90.4 / 93.2.
-        auto ff_wanted = [&](const Instrument& x) {
+        // (instruments that share their records come in pairs whose expansions are ONE launch: the pair's triples count together
+        //  -- C3, us per pass without / with: 128 walkers 66.4 / 70.3, 256: 68.5 / 67.0, 512: 103.8 / 94.4)
+        auto ff_score = [&](size_t i) {
+            const Instrument& x = c->inst[i];
             const vp::InstDev& gx = sel ? x.dev_s : x.dev;
-            const bool pays = c->tune.farfield > 0 || x.ff_cover * (double)Wp * gx.ntiles * gx.ff_nblk * x.ff_items >= 2.0e5;
-            return x.ff_on && c->d_ff && pays;
+            return x.ff_on ? x.ff_cover * (double)Wp * gx.ntiles * gx.ff_nblk * x.ff_items : 0.0;
+        };
+        auto ff_wanted = [&](size_t i) {
+            const Instrument& x = c->inst[i];
+            if (!x.ff_on || !c->d_ff) return false;
+            if (c->tune.farfield > 0) return true;
+            double score = ff_score(i);
+            if (!c->tune.no_shared_prep && !prof) {
+                size_t r0 = i;
+                while (r0 > 0 && c->inst[r0].same_lines_as_prev) --r0;
+                const size_t partner = r0 + ((i - r0) ^ 1);
+                const bool in_run = partner < c->inst.size() && (partner < i ? true : c->inst[partner].same_lines_as_prev) &&
+                                    (partner > i || c->inst[i].same_lines_as_prev);
+                if (in_run && (sel ? c->inst[partner].dev_s : c->inst[partner].dev).ff_members == (sel ? x.dev_s : x.dev).ff_members)
+                    score += ff_score(partner);
+            }
+            return score >= 2.0e5;
         };
         // every instrument's expansions have their own stretch of the workspace (W x its blocks), in instrument order
         size_t ff_off = 0;
@@ -596,7 +614,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             const vp::InstDev& gi = sel ? c->inst[i].dev_s : c->inst[i].dev;
             if (c->inst[i].ff_on) ff_off += (size_t)W * gi.ntiles * gi.ff_nblk * vp::FF_STRIDE;
         }
-        double* ff = ff_wanted(in) ? c->d_ff + ff_off : nullptr;
+        double* ff = ff_wanted(k) ? c->d_ff + ff_off : nullptr;
         if (ff && !ff_made) {                            // the blocks' far-field expansions from the records just made
             c->last_kind = 2;
             vp::InstDev g2 = geom;
@@ -605,7 +623,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             const size_t ffl = vp::farfield_lds_bytes(in.lines.L, in.lines.NCm);
             // the next instrument's too, in the same launch, when it has these line tables (the same records)
             const Instrument* nx = (k + 1 < c->inst.size() && !prof) ? &c->inst[k + 1] : nullptr;
-            if (nx && nx->same_lines_as_prev && !c->tune.no_shared_prep && ff_wanted(*nx) && (sel ? nx->dev_s : nx->dev).ff_members == g2.ff_members) {
+            if (nx && nx->same_lines_as_prev && !c->tune.no_shared_prep && ff_wanted(k + 1) && (sel ? nx->dev_s : nx->dev).ff_members == g2.ff_members) {
                 vp::InstDev g3 = sel ? nx->dev_s : nx->dev;
                 g3.ff = ff + (size_t)W * nbk * vp::FF_STRIDE;
                 const int nbk1 = g3.ntiles * g3.ff_nblk, nbx0 = (nbk + 63) / 64, nbx1 = (nbk1 + 63) / 64;
