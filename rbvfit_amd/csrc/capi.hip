@@ -585,6 +585,8 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         // when the instrument is added); the crossover sits near 2e5 covered (walker, block, item) triples: C2 at 256
         // walkers (0.195e6) 72.7 / 71.5 us, the 40-line FeII fit at 1024 walkers (0.17e6) 164.9 / 161.1, the 20-line one
         // at 1024 (0.09e6) 90.4 / 93.2.
+        // (round 3, after the launch itself got cheaper -- records staged in LDS, faster record preparation in front of it --: on
+        //  from 1.5e5 covered triples: C2 at 256 walkers (1.95e5) 57.2 / 54.9, C4 at 64 (0.9e5) 119.5 / 130.8.)
         // (instruments that share their records come in pairs whose expansions are ONE launch: the pair's triples count together
         //  -- C3, us per pass without / with: 128 walkers 66.4 / 70.3, 256: 68.5 / 67.0, 512: 103.8 / 94.4)
         auto ff_score = [&](size_t i) {
@@ -594,7 +596,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         };
         auto ff_wanted = [&](size_t i) {
             const Instrument& x = c->inst[i];
-            if (!x.ff_on || !c->d_ff) return false;
+            if (!x.ff_on || !c->d_ff || c->tune.farfield == 0) return false;
             if (c->tune.farfield > 0) return true;
             double score = ff_score(i);
             if (!c->tune.no_shared_prep && !prof) {
@@ -606,7 +608,9 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
                 if (in_run && (sel ? c->inst[partner].dev_s : c->inst[partner].dev).ff_members == (sel ? x.dev_s : x.dev).ff_members)
                     score += ff_score(partner);
             }
-            return score >= 2.0e5;
+            // (instruments whose cluster members enter the expansions line by line pay more for the launch: C4 at 64 walkers
+            //  -- 1.8e5 -- 119.5 / 130.3 us, at 512 walkers 636 / 529)
+            return score >= ((sel ? x.dev_s : x.dev).ff_members ? 3.0e5 : 1.5e5);
         };
         // every instrument's expansions have their own stretch of the workspace (W x its blocks), in instrument order
         size_t ff_off = 0;
