@@ -421,6 +421,10 @@ bool walker_applies(const vp_ctx* c, int W) {
     // tiles, 1024 walkers 22.0 vs 29.2 us; 2100 pixels, 6 tiles: 768 walkers 22.7 vs 30.1, 1024: 39.3 vs 33.5; 2800 pixels,
     // 8 tiles: 768 walkers 26.4 vs 33.6, 1024: 38.0 vs 37.6)
     const int layers = (W + 255) / 256;
+    // (two workgroups per CU -- C1's 12 tiles --: a batch that fills a second round of 512 workgroups is still better off than
+    //  through the launches -- C1, us per pass, walker kernel / launches: 768 walkers 35.5 / 36.1, 896: 41.7 / 42.5, 1024: 41.9 /
+    //  44.75; 576: 35.2 / 29.9, 640: 35.3 / 32.1, 1280: 55.5 / 51.6)
+    if (per_cu == 2 && layers == 4) return true;
     return layers <= per_cu && (layers <= 3 || layers <= per_cu - 2);
 }
 
