@@ -265,6 +265,13 @@ int vp_device_id(const vp_ctx* ctx);
  * 1 = walker_kernel (the whole batch in one launch: one instrument, or up to four with identical line tables), 2 = as 0 with farfield_kernel between preparation and tiles
  * (far lines from per-block expansions). */
 int vp_last_launch_kind(const vp_ctx* ctx);
+/* What the far-field expansions of the last lnprob batch covered (first instrument that took any; test / diagnosis hook, it
+ * synchronises and copies the masks back): *variant = 0 none, 1 farfield_kernel<6,false> (lines outside clusters and whole
+ * clusters, |x| >= 30), 2 farfield_kernel<9,true> (narrow-pixel instruments: also the MEMBERS of clusters too near for their
+ * multipole, line by line, |x| >= 14); *covered = (walker, block, line) triples taken from the expansions, *covered_members =
+ * those of them whose line is a member of a multipole cluster (with variant 1 they entered with their whole cluster, with
+ * variant 2 also one by one), *pairs = walkers x blocks x lines.  Any pointer may be NULL. */
+int vp_last_farfield_info(vp_ctx* ctx, int* variant, int64_t* covered, int64_t* covered_members, int64_t* pairs);
 
 /* Text of the last error on this context (or of the last failed vp_ctx_create when ctx is NULL).
  * Valid until the next call on the same context/thread. */

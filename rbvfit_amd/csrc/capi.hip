@@ -59,6 +59,8 @@ struct Tuning {
     int tile_lpt = 1;           // (read when an instrument is added) tile launches hand out the tiles with the most line cores
                                 // first (0: in grid order)
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
+    int flux_farfield = -1;     // vp_model_flux_batch[_device]: far lines from the blocks' expansions as in the lnprob launches: -1 by batch
+                                // size (the lnprob rule), 0 never, 1 whenever the instrument has the tables
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
                                 // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
@@ -74,6 +76,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
     VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
+    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -109,6 +112,8 @@ struct Instrument {
     int ff_items = 0;            // multipole clusters + lines outside clusters: what a pass of the tile kernel walks
     std::vector<double> h_lines; // lambda0 | gamma | f | zfac: with h_idx, what the line records of a walker depend on
     std::vector<int> h_idx;      // N_idx | b_idx | v_idx | method | multipole settings
+    unsigned long long member_mask[2] = {0ull, 0ull};   // lines that are members of multipole clusters (L <= 128: what the
+                                       // far-field masks are compared with, vp_last_farfield_info)
     bool same_lines_as_prev = false;   // this instrument's records ARE the previous instrument's (same line tables):
                                        // its record-preparation launch is skipped (C3: two instruments, one physics)
 };
@@ -173,6 +178,9 @@ struct vp_ctx {
     int policy_W = 0;            // > 0: the launch structure of a batch is chosen as for THIS many rows (a block of a larger batch
                                  // that other contexts share: same structure, hence the same bits, as the whole batch on one context)
     int last_kind = 0;           // launch structure of the last lnprob batch: 0 prep + tile (+ finalize), 1 walker_kernel
+    // the far-field expansions the last lnprob batch made for its FIRST instrument that took any (vp_last_farfield_info):
+    // where they lie in the workspace, rows, blocks per row, which farfield_kernel instance, which instrument
+    struct LastFF { const double* ff = nullptr; int W = 0, nbk = 0, members = 0, inst = -1; } last_ff;
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -300,10 +308,10 @@ void launch_tile(const Instrument& in, const double* lc, const int* flags, doubl
     const vp::InstDev& dev = geom ? *geom : in.dev;
     dim3 grid(W, dev.ntiles, grid_z);
     dim3 block(64 * in.nwaves);
-    if (ff && OUT == 0 && !GENERIC && dev.method == VP_VOIGT_WOFZ) {     // far lines from the blocks' expansions
+    if (ff && OUT != 2 && !GENERIC && dev.method == VP_VOIGT_WOFZ) {     // far lines from the blocks' expansions
         vp::InstDev d2 = dev;
         d2.ff = ff;
-        hipLaunchKernelGGL((vp::tile_kernel<0, 0, false, true>), grid, block, in.lds_bytes, s, d2, lc, flags, out, stride, offset, fin, genflag);
+        hipLaunchKernelGGL((vp::tile_kernel<0, OUT == 1 ? 1 : 0, false, true>), grid, block, in.lds_bytes, s, d2, lc, flags, out, stride, offset, fin, genflag);
         return;
     }
     if (dev.method == VP_VOIGT_FAST) {
@@ -485,6 +493,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     const bool prof = c->profiling;
     size_t m0 = prof ? prof_mark(c, s) : 0;
     c->last_kind = 0;
+    c->last_ff = vp_ctx::LastFF{};
     const int Wp = c->policy_W > 0 ? c->policy_W : W;       // rows the launch structure is chosen for
     if (walker_applies(c, Wp)) {
         c->last_kind = 1;
@@ -628,6 +637,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
             vp::InstDev g2 = geom;
             g2.ff = ff;
             const int nbk = geom.ntiles * geom.ff_nblk;
+            if (c->last_ff.inst < 0) c->last_ff = vp_ctx::LastFF{ff, W, nbk, g2.ff_members, (int)k};
             const size_t ffl = vp::farfield_lds_bytes(in.lines.L, in.lines.NCm);
             // the next instrument's too, in the same launch, when it has these line tables (the same records)
             const Instrument* nx = (k + 1 < c->inst.size() && !prof) ? &c->inst[k + 1] : nullptr;
@@ -885,6 +895,8 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         l = e;
     }
     const int NCm = (int)cl_first.size();
+    for (int k = 0; k < NCm; ++k)
+        for (int l = cl_first[k]; l < cl_first[k] + cl_count[k] && l < 128; ++l) in.member_mask[l >> 6] |= 1ull << (l & 63);
     int *d_clmp, *d_clend, *d_clfirst, *d_clcount;
     UP(int, cl_mp.data(), L, d_clmp) UP(int, cl_end.data(), L, d_clend)
     UP(int, cl_first.data(), cl_first.size(), d_clfirst) UP(int, cl_count.data(), cl_count.size(), d_clcount)
@@ -1357,8 +1369,24 @@ static int enqueue_model_flux(vp_ctx* c, int inst, int W, const double* d_theta,
     launch_prep(c, in, d_theta, W, 0, nullptr, gen ? c->d_genflag : (int*)nullptr, s);
     const vp::FinalizeArgs nofin{};
     const int* gf = gen ? c->d_genflag : (const int*)nullptr;
+    // far lines from the blocks' expansions, as in the lnprob launches (convolved flux; same rule for when the extra launch pays)
+    double* ff = nullptr;
+    c->last_ff = vp_ctx::LastFF{};
+    if (convolved && in.ff_on && c->d_ff && c->tune.flux_farfield != 0) {
+        const double score = in.ff_cover * (double)W * in.dev.ntiles * in.dev.ff_nblk * in.ff_items;
+        if (c->tune.flux_farfield > 0 || score >= (in.dev.ff_members ? 3.0e5 : 1.5e5)) ff = c->d_ff;
+    }
+    if (ff) {
+        vp::InstDev g2 = in.dev;
+        g2.ff = ff;
+        const int nbk = g2.ntiles * g2.ff_nblk;
+        c->last_ff = vp_ctx::LastFF{ff, W, nbk, g2.ff_members, inst};
+        const size_t ffl = vp::farfield_lds_bytes(in.lines.L, in.lines.NCm);
+        if (g2.ff_members) hipLaunchKernelGGL((vp::farfield_kernel<9, true>), dim3((nbk + 63) / 64, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, in.lines, c->d_lc, W);
+        else hipLaunchKernelGGL((vp::farfield_kernel<6, false>), dim3((nbk + 63) / 64, W), dim3(64 * vp::FF_WAVES), ffl, s, g2, in.lines, c->d_lc, W);
+    }
     if (convolved) {
-        launch_tile<1, false>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
+        launch_tile<1, false>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf, nullptr, 1, ff);
         if (gen) launch_tile<1, true>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
     } else {
         launch_tile<2, false>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
@@ -2303,6 +2331,35 @@ int vp_instrument_pixels(const vp_ctx* c, int inst) {
     return c->inst[inst].dev.P;
 }
 int vp_device_id(const vp_ctx* c) { return c ? c->device : -1; }
+int vp_last_farfield_info(vp_ctx* c, int* variant, int64_t* covered, int64_t* covered_members, int64_t* pairs) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (variant) *variant = 0;
+    if (covered) *covered = 0;
+    if (covered_members) *covered_members = 0;
+    if (pairs) *pairs = 0;
+    const vp_ctx::LastFF lf = c->last_ff;
+    if (lf.inst < 0 || !lf.ff || lf.W <= 0 || lf.nbk <= 0) return VP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    const size_t n = (size_t)lf.W * lf.nbk;
+    std::vector<double> h(n * vp::FF_STRIDE);
+    HIP_TRY(c, hipMemcpy(h.data(), lf.ff, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const Instrument& in = c->inst[lf.inst];
+    int64_t cov = 0, mem = 0;
+    for (size_t i = 0; i < n; ++i) {
+        unsigned long long m[2];
+        memcpy(m, h.data() + i * vp::FF_STRIDE + vp::FF_MASK0, sizeof m);
+        cov += __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]);
+        mem += __builtin_popcountll(m[0] & in.member_mask[0]) + __builtin_popcountll(m[1] & in.member_mask[1]);
+    }
+    if (variant) *variant = lf.members ? 2 : 1;
+    if (covered) *covered = cov;
+    if (covered_members) *covered_members = mem;
+    if (pairs) *pairs = (int64_t)n * in.lines.L;
+    return VP_OK;
+}
+
 int vp_last_launch_kind(const vp_ctx* c) {
     if (!c) return -1;
     std::lock_guard<std::mutex> g(c->mu);

@@ -326,6 +326,17 @@ class Engine:
         kind = self._lib.vp_last_launch_kind(self._ctx)
         return {1: "walker", 2: "tiles+farfield", 3: "tiles-multi"}.get(kind, "tiles")
 
+    @property
+    def last_farfield_info(self) -> dict:
+        """What the far-field expansions of the last lnprob batch covered (``vp_last_farfield_info``): ``variant`` 'none',
+        'lines+clusters' (farfield_kernel<6,false>) or 'members' (farfield_kernel<9,true>: narrow-pixel instruments, members
+        of near clusters line by line); ``covered`` / ``covered_members`` (walker, block, line) triples; ``pairs`` all triples."""
+        self._guard()
+        v, a, b, n = C.c_int(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.vp_last_farfield_info(self._ctx, C.byref(v), C.byref(a), C.byref(b), C.byref(n)))
+        return dict(variant={0: "none", 1: "lines+clusters", 2: "members"}[v.value], covered=a.value,
+                    covered_members=b.value, pairs=n.value)
+
     # -- per-kernel timing (HIP events on the launch stream) ------------------------------------
     def profile_enable(self, on: bool = True):
         self._guard()

@@ -33,44 +33,88 @@ def _host_lnlike_from_flux(wl, thetas):
     return total
 
 
+def _posterior_and_wide_walkers(wl, walkers, name):
+    """The batch the full-size tests evaluate: the ensemble a stretch-move burn-in of the device sampler leaves (posterior
+    width: theta standard deviations of 0.005-0.3 instead of SURVEY 8d's 1e-3 ball, so the multipole tiers, far-field masks
+    and line-core flags differ from walker to walker), with every 8th row replaced by a draw of the fuzz tests' width around
+    theta_true (0.2 dex / 3 km/s / 15 km/s, clipped into the prior box)."""
+    nsteps = {"C1": 600, "C2": 200, "C3": 200, "C4": 100}[name]
+    pos = wl.engine.stretch_run(wl.thetas, nsteps, seed=21, store_chain=False)[0]
+    th = np.ascontiguousarray(pos[:walkers])
+    C = wl.ndim // 3
+    rng = np.random.default_rng(77)
+    wide = np.arange(3, walkers, 8)
+    scale = np.concatenate([np.full(C, 0.2), np.full(C, 3.0), np.full(C, 15.0)])
+    th[wide] = np.clip(wl.theta_true + rng.standard_normal((wide.size, wl.ndim)) * scale, wl.lb + 1e-9, wl.ub - 1e-9)
+    return th, wide
+
+
 # BASELINE.json walker counts: C1 512 and C2 1024 on one GPU; C3 2048 and C4 4096 over 8 GPUs -- run here both as
 # the per-GPU share (256 / 512 walkers: what one rank of the sharded job evaluates) and as the whole ensemble on
 # one GPU (the unsharded batch a single-GPU user would submit).
-@pytest.mark.parametrize("name,walkers,n_oracle,n_prop", [("C1", 512, 24, 64), ("C2", 1024, 4, 16),
-                                                         ("C3", 256, 3, 16), ("C3", 2048, 3, 16),
-                                                         ("C4", 32, 2, 4), ("C4", 512, 2, 4), ("C4", 4096, 2, 4)])
+@pytest.mark.parametrize("name,walkers,n_oracle,n_prop", [("C1", 512, 24, 64), ("C2", 1024, 16, 16),
+                                                         ("C3", 256, 16, 16), ("C3", 2048, 16, 16),
+                                                         ("C4", 32, 8, 4), ("C4", 512, 8, 4), ("C4", 4096, 8, 4)])
 def test_full_size_config(name, walkers, n_oracle, n_prop):
     from rbvfit_amd.workloads import make_workload
-    wl = make_workload(name, walkers=walkers)
+    # (the burn-in ensemble has at least 2 D + 2 walkers whatever the batch evaluated afterwards)
+    wl = make_workload(name, walkers=max(walkers, 2 * {"C1": 6, "C2": 24, "C3": 24, "C4": 96}[name] + 64))
     try:
-        th = wl.thetas.copy()
+        th, wide = _posterior_and_wide_walkers(wl, walkers, name)
+        spread = th[np.setdiff1d(np.arange(walkers), wide)].std(axis=0)
+        assert np.median(spread) > 2e-3                # not the 1e-3 ball any more
         th[5, 0] = wl.lb[0] - 0.25                    # out of bounds -> -inf, model not evaluated
         th[7, -1] = wl.ub[-1] + 3.0
         got = wl.engine.lnprob(th)
+        kind, info = wl.engine.last_launch_kind, wl.engine.last_farfield_info
+        # which launch structure the configuration exercises (the automatic choice on this batch size)
+        want_kind = {("C1", 512): "walker", ("C2", 1024): "tiles+farfield", ("C3", 256): "tiles+farfield",
+                     ("C3", 2048): "tiles+farfield", ("C4", 32): "tiles", ("C4", 512): "tiles+farfield",
+                     ("C4", 4096): "tiles+farfield"}[(name, walkers)]
+        assert kind == want_kind, kind
+        if name == "C4" and walkers >= 512:            # narrow pixels: cluster members enter the expansions line by line
+            assert info["variant"] == "members" and info["covered_members"] > 0, info
+        elif kind == "tiles+farfield":
+            assert info["variant"] == "lines+clusters" and info["covered"] > 0, info
         assert got.shape == (walkers,)
         assert np.isneginf(got[5]) and np.isneginf(got[7])
         ok = np.ones(walkers, bool); ok[[5, 7]] = False
         assert np.all(np.isfinite(got[ok]))
-        # oracle on the first rows
+        # oracle on rows spread over the batch: burn-in rows and wide rows, the first, the middle and the last
         vo, insts = _oracle_instruments(wl)
-        ref = vo.lnprob_batch(th[:n_oracle], wl.lb, wl.ub, insts)
-        np.testing.assert_allclose(got[:n_oracle], ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        rows_o = np.unique(np.concatenate([np.arange(0, 4), wide[: n_oracle // 2],
+                                           np.linspace(8, walkers - 1, max(n_oracle - 4 - n_oracle // 2, 2)).astype(int)]))
+        rows_o = rows_o[(rows_o != 5) & (rows_o != 7)]
+        assert rows_o.size >= n_oracle - 2
+        ref = vo.lnprob_batch(th[rows_o], wl.lb, wl.ub, insts)
+        np.testing.assert_allclose(got[rows_o], ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        # the same batch with the far-field expansions forced the other way (on where the rule left them off, off where it
+        # switched them on): against the oracle rows and against the automatic structure
+        if kind != "walker":
+            wl.engine.set_option("farfield", 0 if kind == "tiles+farfield" else 1)
+            other = wl.engine.lnprob(th)
+            assert wl.engine.last_launch_kind == ("tiles" if kind == "tiles+farfield" else "tiles+farfield")
+            if name == "C4":
+                assert (wl.engine.last_farfield_info["variant"] == "members") == (kind == "tiles")
+            wl.engine.set_option("farfield", -1)
+            np.testing.assert_allclose(other[rows_o], ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+            np.testing.assert_allclose(other[ok], got[ok], rtol=1e-12, atol=1e-9)
         # property: lnprob == likelihood recomputed on the host from the engine's model flux
         rows = np.arange(8, 8 + n_prop)
         np.testing.assert_allclose(got[rows], _host_lnlike_from_flux(wl, th[rows]), rtol=1e-11, atol=1e-7)
         # property: permutation of the walkers permutes the result, bit for bit
         perm = np.random.default_rng(3).permutation(walkers)
         assert np.array_equal(wl.engine.lnprob(th[perm]), got[perm])
-        # property: the last rows of the batch, the middle one and a second pass agree with the oracle / repeat exactly
-        # (the large ensembles go through other tile geometries and the finalize launch)
-        far = np.array([walkers // 2, walkers - 1])
-        np.testing.assert_allclose(got[far], vo.lnprob_batch(th[far], wl.lb, wl.ub, insts), rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        # property: a second pass repeats exactly (the large ensembles go through other tile geometries and the finalize launch)
         assert np.array_equal(wl.engine.lnprob(th), got)
-        # flux rows vs oracle
+        # flux rows vs oracle: a burn-in row and a wide row, with the blocks' expansions and without
         for k, inst in enumerate(insts):
-            fl = wl.engine.model_flux(k, th[:2])
-            for i in range(2):
-                np.testing.assert_allclose(fl[i], vo.model_flux(inst.data, th[i], inst.wave), rtol=0, atol=FLUX_ATOL)
+            for ffo in (1, 0):
+                wl.engine.set_option("flux_farfield", ffo)
+                fl = wl.engine.model_flux(k, th[[0, 3]])
+                for i, r in enumerate((0, 3)):
+                    np.testing.assert_allclose(fl[i], vo.model_flux(inst.data, th[r], inst.wave), rtol=0, atol=FLUX_ATOL)
+            wl.engine.set_option("flux_farfield", -1)
     finally:
         wl.engine.close()
 

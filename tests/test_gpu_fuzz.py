@@ -234,6 +234,98 @@ def test_farfield_expansions_agree_with_direct_evaluation(seed):
         np.testing.assert_allclose(got[1][k], ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
 
 
+def _narrow_pixel_case(seed):
+    """C4-like geometry at fuzz size: pixels of 0.1-0.3 km/s (a 192-pixel block is a few Doppler widths wide, so the
+    instrument gets farfield_kernel<9, true>: members of near clusters line by line, 9 terms from |x| >= 14), >= 8 lines in
+    clusters of 3-6 components of the MgII doublet at two or three nearby redshifts, sometimes a damped component and
+    lines outside clusters, theta spreads of the size test_random_configuration uses."""
+    from rbvfit_amd.model import FitConfiguration, VoigtModel
+    rng = np.random.default_rng(4000 + seed)
+    cfg = FitConfiguration()
+    n_sys = 2 + seed % 2
+    for s in range(n_sys):
+        cfg.add_system(round(0.348 + 0.0012 * s * float(rng.uniform(0.6, 1.4)), 5), "MgII", [2796.352, 2803.531],
+                       int(rng.integers(3, 7)))
+    if seed % 4 == 1:                                    # two FeII lines inside the window: lines outside clusters
+        cfg.add_system(0.4515, "FeII", [2600.1729, 2586.650], 2)
+    C = cfg.total_components
+    fwhm = [None, "2.2", "6.5"][seed % 3]
+    model = VoigtModel(cfg, FWHM=fwhm)
+    pix_kms = float(rng.choice([0.1, 0.2, 0.3]))
+    P = int(rng.integers(5000, 12000))
+    centre = float(rng.uniform(3768.0, 3781.0))
+    dlam = centre * pix_kms / 299792.458
+    wave = centre + dlam * (np.arange(P) - P * rng.uniform(0.3, 0.7))
+    if seed % 5 == 2:
+        wave = wave[::-1].copy()
+    N = rng.uniform(12.3, 14.6, C)
+    if seed % 3 == 0:
+        N[int(rng.integers(0, C))] = rng.uniform(18.3, 20.2)          # one damped component
+    b = rng.uniform(3.0, 45.0, C)
+    v = rng.uniform(-180.0, 180.0, C)
+    theta = np.concatenate([N, b, v])
+    lb = np.concatenate([np.full(C, 10.0), np.full(C, 1.0), np.full(C, -400.0)])
+    ub = np.concatenate([np.full(C, 21.0), np.full(C, 150.0), np.full(C, 400.0)])
+    W = 8
+    thetas = np.clip(theta + rng.normal(0, 1, (W, 3 * C)) * np.concatenate([np.full(C, 0.2), np.full(C, 3.0), np.full(C, 15.0)]),
+                     lb + 1e-9, ub - 1e-9)
+    thetas[0] = theta
+    err = rng.uniform(0.02, 0.1, P)
+    return model, wave, err, thetas, lb, ub, rng
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_narrow_pixel_farfield_members_wide_theta(seed):
+    """farfield_kernel<9, true>: forced on, wide theta, asserted to be the instance that ran and to have
+    taken cluster members one by one; lnprob AND the convolved model flux through the expansions against the oracle, and
+    against the launches without expansions / with the plain <6, false> instance."""
+    import rbvfit_amd
+    from oracle import voigt_oracle as vo
+    model, wave, err, thetas, lb, ub, rng = _narrow_pixel_case(seed)
+    data = model.compile().data
+    assert data.n_lines >= 8
+    od = vo.OracleModelData(data.atomic_lambda0, data.atomic_gamma, data.atomic_f, data.z_factors, data.N_indices,
+                            data.b_indices, data.v_indices, data.taps if data.taps is not None else np.zeros(0),
+                            data.lsf_mode, data.voigt_method)
+    flux = vo.model_flux(od, thetas[0], wave) + rng.normal(0, 1, wave.size) * err
+    inst = vo.OracleInstrument.from_error(od, wave, flux, err)
+    ref = vo.lnprob_batch(thetas, lb, ub, [inst])
+    ref_flux = [vo.model_flux(od, thetas[i], wave) for i in range(4)]
+    res = {}
+    for name, opts in (("members", {"farfield": 1}), ("plain", {"farfield": 1, "no_ff_members": 1}), ("off", {"farfield": 0})):
+        with rbvfit_amd.Engine(0) as e:
+            for k, val in opts.items():
+                e.set_option(k, val)                          # (read when the instrument is added)
+            e.set_bounds(lb, ub)
+            e.add_instrument(wave, flux, inst.inv_sigma2, inst.log_inv_sigma2, **data.engine_kwargs())
+            e.set_option("walker", 0)
+            lp = e.lnprob(thetas)
+            kind, info = e.last_launch_kind, e.last_farfield_info
+            e.set_option("geom", 0); e.set_option("finalize", 0)
+            lp_big = e.lnprob(thetas)
+            info_big = e.last_farfield_info
+            e.set_option("flux_farfield", 1 if opts["farfield"] else 0)
+            fl = e.model_flux(0, thetas[:4])
+            info_flux = e.last_farfield_info
+            res[name] = (lp, lp_big, fl, kind, info, info_big, info_flux)
+    lp, lp_big, fl, kind, info, info_big, info_flux = res["members"]
+    assert kind == "tiles+farfield"
+    for i_ in (info, info_big, info_flux):
+        assert i_["variant"] == "members" and i_["covered"] > 0
+    assert res["plain"][3] == "tiles+farfield" and res["plain"][4]["variant"] == "lines+clusters"
+    assert res["off"][3] == "tiles" and res["off"][4]["variant"] == "none" and res["off"][6]["variant"] == "none"
+    # the members instance took lines the plain one had to leave to the tile kernel: cluster members, one by one
+    assert info_big["covered_members"] > res["plain"][5]["covered_members"]
+    for name in ("members", "plain", "off"):
+        a, b_, f = res[name][:3]
+        np.testing.assert_allclose(a, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL, err_msg=name)
+        np.testing.assert_allclose(b_, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL, err_msg=name)
+        for i in range(4):
+            np.testing.assert_allclose(f[i], ref_flux[i], rtol=0, atol=FLUX_ATOL, err_msg=name)
+    for k in (0, 1):
+        np.testing.assert_allclose(res["members"][k], res["off"][k], rtol=1e-12, atol=1e-9)
+
+
 @pytest.mark.parametrize("n_inst", [2, 3, 4])
 def test_several_instruments_in_one_walker_launch(n_inst):
     """Up to four instruments with the same line tables and at most 16 tiles together run as ONE walker_kernel launch
