@@ -22,7 +22,10 @@ C4 4096/8); ``--strong`` fixes the config's TOTAL walker count and splits it W/N
 Timing: W untimed warm-up steps (raised to what the GPU needs to reach steady clocks; the number
 actually run is ``warmup_effective``), then ``repeats`` blocks of EXACTLY K steps, each bracketed
 by barrier + synchronize on both sides and max-reduced over ranks; ``ms_per_step`` is the MEDIAN
-block (>= 0.25 s of timed passes in total, so a short ``--steps`` is not a one-shot sample).
+block (>= ``--min-seconds`` = 2 s of timed passes in total, so a short ``--steps`` is not a one-shot
+sample and the driver's GPU-busy sampler sees the run).  ``value`` is the device-resident rate (theta
+in HBM when the timed region starts: the bench contract); ``value_host_entry`` is the same batch
+through ``vp_lnprob_batch`` with host buffers (the seam north_star names), timed as long.
 One JSON line on rank 0.
 """
 import argparse
@@ -64,6 +67,11 @@ def parse_args(argv=None):
     ap.add_argument("--spread", default="ball", choices=["ball", "posterior"],
                     help="walker positions of the timed passes: 'ball' = SURVEY 8(d)'s 1e-3 ball around theta_true (the default, what "
                          "`value` is defined on), 'posterior' = the ensemble after a burn-in of the device-resident stretch sampler")
+    ap.add_argument("--entry", default="lnprob", choices=["lnprob", "model_flux"],
+                    help="which C-ABI entry a step is: 'lnprob' (vp_lnprob_batch_device: the headline) or 'model_flux' "
+                         "(vp_model_flux_batch_device, the (W, P) convolved model flux: seam 3 of SURVEY 8b, HBM-write-bound)")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="lower bound on the TOTAL timed region (sum of the timed blocks), so that an outside observer sees the GPU busy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs that are not part of `value` (copy bandwidth, host-entry latency, device sampler): "
@@ -212,6 +220,133 @@ def cpu_baseline(wl, budget_s=12.0):
     return base, np.array(vals)
 
 
+def model_flux_main(args, wl, d_theta, stream, rank, world, use_dist, spread_note):
+    """--entry model_flux: a step = the convolved model flux of the rank's W walkers on every instrument
+    (vp_model_flux_batch_device: CompiledVoigtModel.model_flux, voigt_model.py:295-315, batched; consumers
+    unified_results.py:305-369, results_plot.py:383,571), theta resident in HBM, the (W, P) rows left in HBM.  Algorithmic
+    bytes per step = W x sum(P) x 8 written (+ the spectral grids read once per walker as in the lnprob roofline)."""
+    import torch
+    import torch.distributed as dist
+    eng = wl.engine
+    W, D = wl.thetas.shape
+    bufs = [torch.empty((W, P), dtype=torch.float64, device="cuda") for P in wl.pixels]
+
+    def step():
+        for k, b in enumerate(bufs):
+            eng.model_flux_device(k, d_theta.data_ptr(), b.data_ptr(), W, True, stream.cuda_stream)
+
+    def timed(n):
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    t_probe = timed(10) / 10
+    warm_eff = max(args.warmup, int(min(1500, max(20, 0.05 / max(t_probe, 1e-6)))))
+    for _ in range(warm_eff):
+        step()
+    repeats = args.repeats if args.repeats > 0 else int(min(50000, max(3, np.ceil(args.min_seconds / max(args.steps * t_probe, 1e-9)))))
+    ts = [timed(args.steps) for _ in range(repeats)]
+    elapsed = float(np.median(ts))
+    if rank != 0:
+        return 0
+    # live kernel-side timing: HIP events on the launch stream around back-to-back steps, with and without the far-field
+    # expansions serving the flux path
+    def ev_ms(n=100):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n):
+            step()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    step_ms = ev_ms()
+    ff_kind = eng.last_farfield_info["variant"]
+    variants = {}
+    for name, val in (("flux_farfield_off", 0), ("flux_farfield_on", 1)):
+        eng.set_option("flux_farfield", val)
+        for _ in range(20):
+            step()
+        variants[name] = ev_ms()
+    eng.set_option("flux_farfield", -1)
+    bytes_written = 8.0 * W * sum(wl.pixels)
+    bytes_algo = bytes_written + W * sum(16 * P for P in wl.pixels) + 8 * D * W       # + wave and 1/wave... read once per walker-eval
+    achieved = bytes_written / (step_ms * 1e-3) / 1e9
+    roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                kernel="vp::tile_kernel<0, 1, false, %s> (+ prep_lines_kernel%s, the generic instance's empty launch)" % (
+                    "true" if ff_kind != "none" else "false", ", farfield_kernel" if ff_kind != "none" else ""),
+                avg_kernel_ms=step_ms, kernel_timing="HIP events on the launch stream around 100 back-to-back steps: the WHOLE step "
+                "(all its launches), not the tile kernel alone -- profiles/ has the rocprofv3 per-kernel means",
+                algorithmic_bytes_per_launch=bytes_written, bytes_written_per_step=bytes_written,
+                bytes_with_grid_reads_per_step=bytes_algo, farfield=ff_kind,
+                ms_per_step_by_flux_farfield=variants,
+                note="algorithmic bytes = the (W, P) float64 rows written; the arithmetic in front of the store is the lnprob path's "
+                     "(tau -> exp -> LSF), so this entry is bound by the same fp64 VALU work, not by the store")
+    src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    roof["measured_copy_GBps"] = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    # host variant: vp_model_flux_batch (theta H2D, rows D2H -- W x P x 8 bytes over PCIe per call)
+    nh = 5 if sum(wl.pixels) * W > (1 << 24) else 20
+    wl.engine.model_flux(0, wl.thetas[: min(W, 64)])
+    th0 = time.perf_counter()
+    for _ in range(nh):
+        for k in range(len(wl.pixels)):
+            got = wl.engine.model_flux(k, wl.thetas)
+    host_s = (time.perf_counter() - th0) / nh
+    line = {
+        "metric": "model_flux walker-evals/sec", "value": W * world * args.steps / elapsed, "unit": "evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warm_eff, "repeats": repeats,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": WORKLOAD_LABEL[args.config] + " -- entry model_flux (vp_model_flux_batch_device, convolved)",
+                   "walkers_per_gpu": W, "walkers_total": W * world, "ndim": D, "n_lines": wl.n_lines, "pixels": wl.pixels,
+                   "parallelism": f"walker-shard x{world}"},
+        "walker_spread": spread_note,
+        "value_host_entry": W / host_s, "host_entry_ms_per_call": 1e3 * host_s,
+        "host_entry_note": "vp_model_flux_batch: theta H2D + kernels + (W, P) rows D2H over PCIe (%.1f MB per call)" % (bytes_written / 1e6),
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import voigt_oracle as vo           # checker / baseline only, never the product
+        insts = _oracle_instruments(vo, _describe(wl))
+        n, t0 = 0, time.perf_counter()
+        worst = 0.0
+        while True:
+            i = n % W
+            for k, inst in enumerate(insts):
+                ref = vo.model_flux(inst.data, wl.thetas[i], inst.wave)
+                if n < 8:
+                    worst = max(worst, float(np.max(np.abs(ref - (got[i] if k == len(insts) - 1 else wl.engine.model_flux(k, wl.thetas[i])[0])))))
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or n >= 20 * W:
+                break
+        line["cpu_baseline"] = dict(value=n / dt, unit="model_flux walker-evals/s", cores=1, kind="port",
+                                    sample=f"{n} serial model_flux calls over the {wl.name} walker rows ({dt:.1f} s, numpy/scipy oracle)")
+        line["parity_vs_cpu_baseline_max_abs_flux"] = worst
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def rank_main(args):
     # The CPU fan-out leg forks its workers BEFORE anything touches the GPU (a context is not
     # fork-safe and forked children must not hold the device); they idle until the bench is done.
@@ -283,6 +418,13 @@ def rank_main(args):
         wl.thetas = burned_in()
         spread_note = "ensemble after a stretch-move burn-in (posterior width)"
     d_theta = torch.from_numpy(wl.thetas).cuda()
+    if args.entry == "model_flux":
+        rc = model_flux_main(args, wl, d_theta, stream, rank, world, use_dist, spread_note)
+        if pool is not None:
+            pool.terminate(); pool.join()
+        if use_dist:
+            dist.barrier(); dist.destroy_process_group()
+        return rc
     d_out = torch.empty(W, dtype=torch.float64, device="cuda")
     gathered = torch.empty(W * world, dtype=torch.float64, device="cuda") if use_dist else None
     torch.cuda.synchronize()
@@ -350,7 +492,9 @@ def rank_main(args):
     warm_eff = max(args.warmup, int(min(1500, max(20, 0.05 / max(t_probe, 1e-6)))))
     for _ in range(warm_eff):
         strict_step()
-    repeats = args.repeats if args.repeats > 0 else int(min(200, max(3, np.ceil(0.25 / max(args.steps * t_probe, 1e-9)))))
+    # timed region: blocks of exactly --steps passes, as many as --min-seconds of passes need (>= 2 s by default: the driver's
+    # GPU-busy sampler and its own clock can then corroborate the line)
+    repeats = args.repeats if args.repeats > 0 else int(min(50000, max(3, np.ceil(args.min_seconds / max(args.steps * t_probe, 1e-9)))))
     elapsed, block_times = blocks(strict_step, args.steps, repeats, drain=strict_drain)
     rccl_ms = None
     if direct is not None:
@@ -459,6 +603,46 @@ def rank_main(args):
                                       "multipole and far-field expansions execute far fewer (profiles/*_pmc.json has the "
                                       "instruction counts), so this is a throughput statement, not VALU utilisation")
         host_rate = host_lat = sampler_steps = slice_info = None
+        if not args.no_extras or os.environ.get("BENCH_HOST_ENTRY") == "1":
+            # ---- the same batch through the host-buffer entry (north_star's seam: the sampler ships the (W, D) theta batch through
+            # the C ABI and gets (W,) lnprob back): wall time around vp_lnprob_batch calls made back to back, as an ensemble
+            # sampler makes them, for >= --min-seconds; theta H2D (zero-copy reads over PCIe), kernels, lnprob D2H and the
+            # completion wait are all inside.  Through the Python wrapper (what emcee's vectorize=True sees) and through the
+            # bare ctypes function with prebuilt arguments (what a C caller sees).
+            import ctypes as C
+            th_host = np.ascontiguousarray(wl.thetas)
+            for _ in range(20):
+                ref_host = wl.engine.lnprob(th_host)
+            t_call = 0.0
+            for _ in range(20):
+                th0 = time.perf_counter(); wl.engine.lnprob(th_host); t_call += (time.perf_counter() - th0) / 20
+            ncall = int(max(50, min(200000, np.ceil(args.min_seconds / max(t_call, 1e-7)))))
+            th0 = time.perf_counter()
+            for _ in range(ncall):
+                wl.engine.lnprob(th_host)
+            wall = time.perf_counter() - th0
+            host_rate = W * ncall / wall
+            nlat = min(ncall, 2000)
+            lat = np.empty(nlat)
+            for i in range(nlat):
+                th0 = time.perf_counter(); wl.engine.lnprob(th_host); lat[i] = time.perf_counter() - th0
+            lat.sort()
+            out_raw = np.empty(W)
+            fn, ctx = wl.engine._lib.vp_lnprob_batch, wl.engine._ctx
+            pa, pb = C.c_void_p(th_host.ctypes.data), C.c_void_p(out_raw.ctypes.data)
+            nraw = min(ncall, 5000)
+            th0 = time.perf_counter()
+            for _ in range(nraw):
+                fn(ctx, W, D, pa, pb)
+            raw_us = 1e6 * (time.perf_counter() - th0) / nraw
+            assert np.array_equal(np.nan_to_num(out_raw), np.nan_to_num(ref_host)), "raw C-ABI call differs from the wrapper"
+            host_lat = dict(us_per_call=1e6 * wall / ncall, calls=ncall, seconds=wall, walkers_per_call=W,
+                            median_us=1e6 * float(np.median(lat)), p10_us=1e6 * float(lat[nlat // 10]),
+                            p90_us=1e6 * float(lat[(9 * nlat) // 10]), latency_sample=nlat,
+                            us_per_call_bare_cabi=raw_us, python_wrapper_us=1e6 * wall / ncall - raw_us,
+                            us_per_pass_device_resident=1e3 * step_ev_ms,
+                            note="back-to-back vp_lnprob_batch calls with host theta / host lnprob (Engine.lnprob); bare_cabi = the ctypes "
+                                 "function with prebuilt arguments; device_resident = the same batch with theta and lnprob left in HBM")
         if not args.no_extras:
             # measured device copy bandwidth next to the vendor peak (read + write of a 1 GiB buffer)
             src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
@@ -472,20 +656,6 @@ def rank_main(args):
             torch.cuda.synchronize()
             roof["measured_copy_GBps"] = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
             del src, dst
-            # PCIe-inclusive rate through the host-buffer entry (never `value`): wall time around
-            # vp_lnprob_batch including H2D theta + D2H lnprob, 100 calls after 5 warm-ups
-            ncall = 100 if args.config in ("C0", "C1") else 10
-            for _ in range(3):
-                wl.engine.lnprob(wl.thetas)
-            lat = []
-            for _ in range(ncall):
-                th0 = time.perf_counter()
-                wl.engine.lnprob(wl.thetas)
-                lat.append(time.perf_counter() - th0)
-            lat = np.sort(np.array(lat))
-            host_rate = W / float(np.median(lat))
-            host_lat = dict(median_us=1e6 * float(np.median(lat)), p10_us=1e6 * float(lat[ncall // 10]),
-                            p90_us=1e6 * float(lat[(9 * ncall) // 10]), calls=ncall, walkers_per_call=W)
 
             # the walker loop itself on the GPU (vp_stretch_run): real ensemble steps per second, two
             # half-ensemble passes per step, proposals and accept/reject in HBM -- not part of `value`
@@ -578,9 +748,13 @@ def rank_main(args):
             "slice_sampler": slice_info,
             "slice_sampler_note": "device-resident ensemble slice sampling (vp_slice_run, zeus' differential move): ensemble steps/s, "
                                   "lnprob evaluations per walker and step, and the evaluations/s they amount to",
+            "value_host_entry": host_rate,
+            "value_definition": "`value`: theta resident in HBM when the timed region starts and lnprob left in HBM (vp_lnprob_batch_device; the "
+                                "bench contract's definition, PCIe-inclusive rates are never `value`).  `value_host_entry`: the same batch through "
+                                "vp_lnprob_batch with host buffers -- what north_star's sampler loop and SURVEY 8(d)'s 'wall time around "
+                                "vp_lnprob_batch including H2D/D2H' describe (emcee vectorize=True, the INTEGRATION.md stub) --, timed over as "
+                                "many seconds; both are first-class numbers of this line",
             "seam_evals_per_sec": host_rate,
-            "seam_note": "what a caller of the reference's seam gets: vp_lnprob_batch with host buffers (emcee vectorize=True, the "
-                         "INTEGRATION.md stub), H2D theta + kernels + D2H lnprob + sync per call -- `value` is the device-resident rate",
             "host_entry_evals_per_sec_pcie_inclusive": host_rate,
             "host_entry_latency": host_lat,
             "walker_spread": spread_note,

@@ -42,7 +42,7 @@ SIGNATURES = {
     "vp_add_instrument": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp,
                                     _ip, _ip, _ip, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "vp_update_spectrum": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),
-    "vp_lnprob_batch": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp]),
+    "vp_lnprob_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),     # (theta, out: plain addresses)
     "vp_lnprob_batch_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vp_gather_create": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vp_gather_connect": (C.c_int, [_ctx, C.c_void_p, C.c_int]),

@@ -21,6 +21,15 @@
 namespace {
 
 thread_local std::string g_create_error;
+#ifdef VP_STAMPS
+// diagnostic build: wall-clock stamps of the last vp_lnprob_batch call (ns since its entry): 0 theta staged, 1 launches enqueued,
+// 2 first output row seen, 3 all rows seen / completion, 4 copied out
+double g_host_stamps[8];
+std::chrono::steady_clock::time_point g_host_t0;
+#define VP_HSTAMP(k) g_host_stamps[k] = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - g_host_t0).count()
+#else
+#define VP_HSTAMP(k) do { } while (0)
+#endif
 
 // Tuning / experiment knobs.  Defaults come from RBVFIT_AMD_* environment variables read ONCE, when the
 // context is created (never on the per-call path); vp_set_option changes them per context.
@@ -51,8 +60,11 @@ struct Tuning {
                                 // half-step; tested with the contexts on ONE device, where it measured no faster than events because the
                                 // contexts' kernels share the CUs (C1, 2 contexts: 49.9 vs 39.5 us per half-step; C3 at 2048 walkers:
                                 // 257 vs 272); across devices it uses system-scope fences and has never run
-    int host_spin = 1;          // host-buffer entries wait for their batch by spinning on a host-mapped completion word the stream writes
-                                // (0: hipStreamSynchronize; measured 512-walker C1 call 42.7 -> ~33 us)
+    int host_spin = 2;          // how the host-buffer entries learn that their batch is done: 0 hipStreamSynchronize; 1 spin on a host-mapped
+                                // completion word the stream writes behind the batch (512-walker C1 call 42.7 -> ~39.5 us); 2 zero-copy batches:
+                                // spin on the OUTPUT ROWS themselves -- they are pre-set to a NaN pattern no arithmetic produces and every
+                                // row is written exactly once, by the launch that finishes it: no completion packet behind the kernel and no
+                                // hipStreamWriteValue32 call in front of it (falls back to 1 when an input carries that pattern)
     int no_ff_members = 0;      // (read when an instrument is added) never take cluster members into the far-field expansions one by one
     int tile_multi = -1;        // tiles of several instruments in one launch (tile_kernel_multi): -1 by batch size, 0 never, 1 whenever possible
     int gather_plain = 0;       // vp_gather_create: ordinary device memory for the gathered vector and flags instead of fine-grained
@@ -153,12 +165,18 @@ struct vp_ctx {
     int total_tiles_g[2] = {0, 0};
     int total_tiles_w = 0;       // tiles of all instruments in the single-wave geometry (tile_kernel_multi)
     double* h_pinned = nullptr;  // staging for theta / out
+    double* h_pinned_dev = nullptr;   // ... as the device sees it (zero-copy batches)
     size_t h_pinned_bytes = 0;
     // completion of a host-buffer call without an interrupt: the stream writes a sequence number to a host-mapped word
     // behind the batch (hipStreamWriteValue32), the calling thread spins on it (host_wait)
     uint32_t* h_done = nullptr;
     uint32_t done_seq = 0;
     bool done_armed = false;     // the last batch enqueued carries a completion write
+    // host_spin = 2: the last batch's output rows are what the host polls (lnprob_host_begin / host_wait)
+    bool sentinel_armed = false;
+    int sentinel_W = 0;
+    const double* sentinel_out = nullptr;
+    bool sentinel_unsafe = false;    // some static input (bounds, spectra, line tables, taps) carries the sentinel's NaN payload
     // direct-write gather of the lnprob vector between the ranks of a multi-process job (vp_gather_*)
     struct Gather {
         int W = 0, world = 0, rank = 0, seq = 0;
@@ -231,6 +249,20 @@ double neumaier_sum(const double* v, int n) {
     return s + comp;
 }
 
+// The NaN the output rows of a zero-copy host batch are pre-set to (host_spin = 2).  Hardware-made NaNs are the default quiet NaN
+// and NaN inputs travel through arithmetic with their payload (quieted, sign possibly flipped): an output can only equal
+// the pattern if an INPUT carried this payload, and every entry point that takes doubles looks for it.
+constexpr uint64_t VP_SENTINEL_BITS = 0x7FF8A5C3965A3C69ull;
+inline bool carries_sentinel(const double* v, size_t n) {
+    bool hit = false;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t b;
+        std::memcpy(&b, v + i, 8);
+        hit |= ((b & 0x7FFFFFFFFFFFFFFFull) | 0x0008000000000000ull) == VP_SENTINEL_BITS;
+    }
+    return hit;
+}
+
 int ensure_scratch(vp_ctx* c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return VP_OK;
     if (c->d_scratch) HIP_TRY(c, hipFree(c->d_scratch));
@@ -243,7 +275,7 @@ int ensure_scratch(vp_ctx* c, size_t bytes) {
 int ensure_pinned(vp_ctx* c, size_t bytes) {
     if (bytes <= c->h_pinned_bytes) return VP_OK;
     if (c->h_pinned) HIP_TRY(c, hipHostFree(c->h_pinned));
-    c->h_pinned = nullptr; c->h_pinned_bytes = 0;
+    c->h_pinned = nullptr; c->h_pinned_bytes = 0; c->h_pinned_dev = nullptr;
     HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, bytes, hipHostMallocDefault));
     c->h_pinned_bytes = bytes;
     return VP_OK;
@@ -822,6 +854,7 @@ int vp_set_bounds(vp_ctx* c, int D, const double* lb, const double* ub) {
         c->d_theta = c->d_out = c->d_lc = c->d_partial = nullptr; c->d_flags = nullptr; c->capW = 0;
     }
     c->D = D;
+    if (carries_sentinel(lb, D) || carries_sentinel(ub, D)) c->sentinel_unsafe = true;
     c->h_lb.assign(lb, lb + D);
     c->h_ub.assign(ub, ub + D);
     for (auto& in : c->inst) analyse_generic(c, in);
@@ -848,6 +881,9 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         if (N_idx[l] < 0 || N_idx[l] >= c->D || b_idx[l] < 0 || b_idx[l] >= c->D || v_idx[l] < 0 || v_idx[l] >= c->D)
             return fail(c, VP_EINVAL, "vp_add_instrument: theta index of line " + std::to_string(l) + " outside [0, D)");
     }
+    if (carries_sentinel(wave, P) || carries_sentinel(flux, P) || carries_sentinel(inv_sigma2, P) || carries_sentinel(lambda0, L) ||
+        carries_sentinel(gamma, L) || carries_sentinel(f, L) || carries_sentinel(zfac, L) || (taps && K > 0 && carries_sentinel(taps, K)))
+        c->sentinel_unsafe = true;
     HIP_TRY(c, hipSetDevice(c->device));
     Instrument in;
     int rc;
@@ -1098,6 +1134,7 @@ int vp_update_spectrum(vp_ctx* c, int inst, const double* flux, const double* in
     if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_update_spectrum: instrument index out of range");
     if (!flux || !inv_sigma2 || !log_inv_sigma2) return fail(c, VP_EINVAL, "vp_update_spectrum: NULL array");
     Instrument& in = c->inst[inst];
+    if (carries_sentinel(flux, in.dev.P) || carries_sentinel(inv_sigma2, in.dev.P)) c->sentinel_unsafe = true;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(in.d_flux, flux, (size_t)in.dev.P * sizeof(double), hipMemcpyHostToDevice));
@@ -1297,13 +1334,29 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta) {
     if ((rc = ensure_pinned(c, tb + ob))) return rc;
     std::memcpy(c->h_pinned, theta, tb);
     double* h_out = c->h_pinned + (size_t)W * D;
+    VP_HSTAMP(0);
+    c->done_armed = false;
+    c->sentinel_armed = false;
     // zerocopy_max defaults to 1 MiB; measured: 512 walkers x 6 parameters 50 us/call zero-copy vs 58 us with copies
     if (tb <= (size_t)std::max(0l, c->tune.zerocopy_max) && !c->tune.no_zerocopy) {
         // up to 1 MiB of theta: the kernels read theta from / write lnprob to the pinned (host-coherent)
         // buffer directly over PCIe -- no H2D/D2H copy commands on the latency path
-        double* dp = nullptr;
-        HIP_TRY(c, hipHostGetDevicePointer((void**)&dp, c->h_pinned, 0));
+        if (!c->h_pinned_dev) HIP_TRY(c, hipHostGetDevicePointer((void**)&c->h_pinned_dev, c->h_pinned, 0));
+        double* dp = c->h_pinned_dev;
+        // completion by the output rows themselves: every row is written exactly once per batch (out-of-bounds rows by the
+        // launch that applies the prior, the others by the launch -- or the walker's last tile -- that finishes them)
+        const bool poll_rows = c->tune.host_spin >= 2 && !c->sentinel_unsafe && !c->gather_rep && !carries_sentinel(theta, (size_t)W * D);
+        if (poll_rows) {
+            uint64_t* o = reinterpret_cast<uint64_t*>(h_out);
+            for (int i = 0; i < W; ++i) o[i] = VP_SENTINEL_BITS;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+        }
         if ((rc = enqueue_lnprob(c, W, dp, dp + (size_t)W * D, c->stream))) return rc;
+        if (poll_rows) {
+            c->sentinel_armed = true; c->sentinel_W = W; c->sentinel_out = h_out;
+            VP_HSTAMP(1);
+            return VP_OK;
+        }
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_theta, c->h_pinned, tb, hipMemcpyHostToDevice, c->stream));
         if ((rc = enqueue_lnprob(c, W, c->d_theta, c->d_out, c->stream))) return rc;
@@ -1311,7 +1364,6 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta) {
     }
     // completion word behind the batch (the command processor writes it once everything before it on the stream is done
     // and visible to the host); where the runtime refuses, host_wait falls back to hipStreamSynchronize
-    c->done_armed = false;
     if (c->tune.host_spin) {
         if (!c->h_done) {
             if (hipHostMalloc((void**)&c->h_done, 64, hipHostMallocMapped) != hipSuccess) { c->h_done = nullptr; (void)hipGetLastError(); }
@@ -1324,17 +1376,41 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta) {
         else
             (void)hipGetLastError();
     }
+    VP_HSTAMP(1);
     return VP_OK;
 }
 // wait for the batch lnprob_host_begin enqueued: spin on the completion word (no interrupt, no driver call on the way),
 // hipStreamSynchronize when the word is not armed or has not come after 20 ms (a long batch: the interrupt is cheap then)
 static int host_wait(vp_ctx* c) {
+    if (c->sentinel_armed) {
+        // rows land in any order; walk them once, waiting at the first one that is still the pattern
+        c->sentinel_armed = false;
+        const uint64_t* o = reinterpret_cast<const uint64_t*>(c->sentinel_out);
+        const int W = c->sentinel_W;
+        const auto t0 = std::chrono::steady_clock::now();
+        int i = 0;
+        for (unsigned int spins = 0; i < W; ++spins) {
+            while (i < W && __atomic_load_n(o + i, __ATOMIC_ACQUIRE) != VP_SENTINEL_BITS) {
+#ifdef VP_STAMPS
+                if (i == 0) VP_HSTAMP(2);
+#endif
+                ++i;
+            }
+            if (i == W) { VP_HSTAMP(3); return VP_OK; }
+            __builtin_ia32_pause();
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+        if (i == W) return VP_OK;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));     // (a long batch: the interrupt is cheap then; everything is written behind it)
+        return VP_OK;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->done_armed) {
         const uint32_t want = c->done_seq;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned int spins = 0;; ++spins) {
-            if (__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) == want) return VP_OK;
+            if (__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) == want) { VP_HSTAMP(3); return VP_OK; }
             __builtin_ia32_pause();
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
         }
@@ -1346,6 +1422,7 @@ static int lnprob_host_end(vp_ctx* c, int W, int D, double* out) {
     int rc;
     if ((rc = host_wait(c))) return rc;
     std::memcpy(out, c->h_pinned + (size_t)W * D, (size_t)W * sizeof(double));
+    VP_HSTAMP(4);
     return VP_OK;
 }
 
@@ -1355,6 +1432,9 @@ int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
     int rc = check_batch_args(c, W, D, theta, out);
     if (rc) return rc;
     if (W == 0) return VP_OK;
+#ifdef VP_STAMPS
+    g_host_t0 = std::chrono::steady_clock::now();
+#endif
     if ((rc = lnprob_host_begin(c, W, D, theta))) return rc;
     return lnprob_host_end(c, W, D, out);
 }
@@ -1840,6 +1920,7 @@ extern "C" int vp_debug_read_slice_stamps(long long* out, int n) {
     hipDeviceSynchronize();
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(vp::g_slice_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
+extern "C" int vp_debug_host_stamps(double* out8) { std::memcpy(out8, g_host_stamps, sizeof g_host_stamps); return 0; }
 // diagnostic build only: the walker kernel's phase stamps of the last launch (shader clock), (walker, wave, stage)
 extern "C" int vp_debug_read_stamps(long long* out, int n) {
     const size_t bytes = sizeof(long long) * (size_t)std::min(n, vp::STAMP_W * vp::STAMP_WAVES * vp::STAMP_STAGES);

@@ -1359,6 +1359,13 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int i = base + r * 64 + lane;
+#ifndef VP_NO_SMALL_EXP
+            // a chunk in the far wings of every line (|tau| < 2^-10 in all its lanes; a NaN fails the test): short Taylor form
+            if (!pending[r] && __ballot(!(fabs(tau[r]) < EXP_SMALL_MAX)) == 0ull) {
+                if (i < n_eval) fl[i] = exp_neg_small(tau[r]);
+                continue;
+            }
+#endif
             // voigt_model.py:217; a NaN tau (NaN pixel, poisoned line) stays NaN as in the reference
             if (i < n_eval) fl[i] = (pending[r] || tau[r] != tau[r]) ? tau[r] : exp_neg_tab(tau[r], etab);
         }
