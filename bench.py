@@ -768,7 +768,10 @@ def rank_main(args):
                                              "rbvfit_amd.dist.DirectGather / vp_gather_*") if direct is not None else
                                             "strict: blocking all_gather_into_tensor of the per-walker lnprob after every pass",
                               "direct_gather": direct is not None, "direct_gather_unavailable_because": direct_reason or None,
-                              "ms_per_step_blocking_rccl_all_gather": rccl_ms,
+                              "direct_gather_probe": direct_reason or "clean: two passes matched all_gather_into_tensor on every rank",
+                              "ranks_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
+                              "visible_gpus_on_rank0": torch.cuda.device_count(),
+                              "ms_per_step_blocking_rccl_all_gather": rccl_ms if rccl_ms is not None else line["ms_per_step"],
                               "ms_per_step_island_form": island_ms,
                               "island_form": f"async all_gather_into_tensor of {gather_every}-step chunks, double-buffered, "
                                              "overlapped with the following passes (rbvfit_amd.dist.PipelinedGather)",

@@ -277,7 +277,9 @@ int vp_last_farfield_info(vp_ctx* ctx, int* variant, int64_t* covered, int64_t* 
  * Valid until the next call on the same context/thread. */
 const char* vp_last_error(const vp_ctx* ctx);
 
-/* Library version string, e.g. "rbvfit_amd 0.1.0 (gfx950)". */
+/* Library version string: "rbvfit_amd " RBVFIT_AMD_VERSION " (gfx950, hip)".  One number for the header, the library and the
+ * Python package (rbvfit_amd.__version__); tests/test_cabi_symbols.py checks that they agree. */
+#define RBVFIT_AMD_VERSION "0.4.0"
 const char* vp_version(void);
 
 #ifdef __cplusplus

@@ -5,6 +5,6 @@ from ._lib import (RbvfitAmdError, RbvfitAmdLibraryError, LSF_NONE, LSF_SCIPY_NE
 from .engine import Engine, MultiEngine, device_count
 from . import model, vfit, sampler, dist, lsf, atomic, workloads, cog  # noqa: F401  (host mirror of the reference interface)
 
-__version__ = "0.2.0"
+__version__ = "0.4.0"     # = RBVFIT_AMD_VERSION of include/rbvfit_amd.h = what vp_version() reports
 __all__ = ["Engine", "MultiEngine", "device_count", "RbvfitAmdError", "RbvfitAmdLibraryError", "LIB_PATH",
            "LSF_NONE", "LSF_SCIPY_NEAREST", "LSF_ASTROPY_EXTEND", "VOIGT_WOFZ", "VOIGT_FAST"]

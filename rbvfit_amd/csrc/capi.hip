@@ -740,7 +740,7 @@ int check_batch_args(vp_ctx* c, int W, int D, const void* a, const void* b) {
 
 extern "C" {
 
-const char* vp_version(void) { return "rbvfit_amd 0.3.0 (gfx950, hip)"; }
+const char* vp_version(void) { return "rbvfit_amd " RBVFIT_AMD_VERSION " (gfx950, hip)"; }
 
 int vp_device_count(void) {
     int n = 0;

@@ -132,10 +132,32 @@ constexpr WingTable make_wing_table() {
 }
 __constant__ const WingTable g_wing = make_wing_table();
 
+// Sum over the 64 lanes of a wave, the same value in every lane.  Data-parallel-primitive moves inside the 16-lane rows
+// (lane ^ 1, lane ^ 2, 7 - lane, 15 - lane), then row 0 into row 1 and row 2 into row 3 (row_bcast:15), rows 0-1 into rows 2-3
+// (row_bcast:31) and lane 63 read back: 18 VALU instructions and two v_readlane, no LDS traffic.  The shuffle form
+// (__shfl_xor = ds_bpermute: six dependent LDS round trips with a compare / select / shift each, ~42 instructions) sat at the very
+// end of every tile wave's life -- in walker_kernel on the workgroup's critical path.  The tree is fixed, so results stay
+// reproducible run to run; it is not the butterfly's tree, so the last bit of a tile's partial sum can differ from round 3's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
+#ifdef VP_SHFL_WAVE_SUM
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+#else
+    v += dpp_f64<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xf>(v);         // row_half_mirror
+    v += dpp_f64<0x140, 0xf>(v);         // row_mirror: every lane holds its row's sum
+    v += dpp_f64<0x142, 0xa>(v);         // row_bcast:15 into rows 1 and 3 (the other rows add the 0 of the masked move)
+    v += dpp_f64<0x143, 0xc>(v);         // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+#endif
 }
 
 // Fill one record from (T, a).  ONE LANE PER RECORD: a wave prepares up to 64 records at once, so

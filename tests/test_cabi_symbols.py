@@ -34,6 +34,16 @@ def test_library_exports_every_declared_symbol():
     assert b"rbvfit_amd" in lib.vp_version()
 
 
+def test_one_version_string_everywhere():
+    """Header macro, vp_version() of the built library and the Python package carry the same number."""
+    import rbvfit_amd
+    from rbvfit_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "rbvfit_amd.h")).read()
+    ver = re.search(r'#define\s+RBVFIT_AMD_VERSION\s+"([^"]+)"', hdr).group(1)
+    assert rbvfit_amd.__version__ == ver
+    assert _lib.load().vp_version().decode() == f"rbvfit_amd {ver} (gfx950, hip)"
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from rbvfit_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
