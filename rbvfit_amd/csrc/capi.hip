@@ -340,6 +340,16 @@ void launch_tile(const Instrument& in, const double* lc, const int* flags, doubl
     const vp::InstDev& dev = geom ? *geom : in.dev;
     dim3 grid(W, dev.ntiles, grid_z);
     dim3 block(64 * in.nwaves);
+#ifndef VP_NO_TILE1
+    if (OUT == 0 && !GENERIC && in.nwaves == 1 && grid_z == 1) {        // single-wave tiles: the kernel compiled for them alone
+        vp::Tile1Args a{dev, lc, flags, genflag, vp::TileTail{out, stride, offset, fin}};
+        a.I.ff = ff;
+        if (dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::tile_kernel1<1, false>), grid, block, in.lds_bytes, s, a);
+        else if (ff) hipLaunchKernelGGL((vp::tile_kernel1<0, true>), grid, block, in.lds_bytes, s, a);
+        else hipLaunchKernelGGL((vp::tile_kernel1<0, false>), grid, block, in.lds_bytes, s, a);
+        return;
+    }
+#endif
     if (ff && OUT != 2 && !GENERIC && dev.method == VP_VOIGT_WOFZ) {     // far lines from the blocks' expansions
         vp::InstDev d2 = dev;
         d2.ff = ff;

@@ -132,6 +132,29 @@ constexpr WingTable make_wing_table() {
 }
 __constant__ const WingTable g_wing = make_wing_table();
 
+// A kernel argument read from the kernarg segment AT THE POINT OF USE (a scalar load; the empty asm keeps the compiler from
+// moving it up).  By-value kernel parameters are loaded at entry and then live -- in these kernels: are spilled to VGPR lanes and
+// reloaded, a VALU instruction each time -- until their last use; for arguments that are needed once per pass or only when the
+// tile is done, loading them again is cheaper than keeping them.  tile_kernel1 (InstDev at offset 0 of its argument struct).
+template <class T>
+__device__ __forceinline__ T late_kernarg(size_t byte_offset) {
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "read as 32-bit words");
+    T v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned int __attribute__((address_space(4)))* p =
+        (const unsigned int __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    unsigned int* d = reinterpret_cast<unsigned int*>(&v);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) d[i] = p[byte_offset / 4 + i];
+#else
+    (void)byte_offset;
+    __builtin_memset(&v, 0, sizeof(T));
+#endif
+    return v;
+}
+#define VP_LATE_FIELD(LATE, I, field) ((LATE) ? late_kernarg<decltype((I).field)>(offsetof(InstDev, field)) : (I).field)
+
 // Sum over the 64 lanes of a wave, the same value in every lane.  Data-parallel-primitive moves inside the 16-lane rows
 // (lane ^ 1, lane ^ 2, 7 - lane, 15 - lane), then row 0 into row 1 and row 2 into row 3 (row_bcast:15), rows 0-1 into rows 2-3
 // (row_bcast:31) and lane 63 read back: 18 VALU instructions and two v_readlane, no LDS traffic.  The shuffle form
@@ -1100,7 +1123,8 @@ __device__ __forceinline__ void lsf_block(const InstDev& I, const double* __rest
 // 48 B keeps the 16-byte reads conflict-free (8 lanes x 16 B cover the 32 banks once).  Per output the taps are
 // accumulated in ascending order, as in the plain loop.
 constexpr int LSF_PX = 6;
-template <int OUT, bool EARLY>    // EARLY: the observed pixels are requested ahead of the taps (walker_kernel, below)
+template <int OUT, bool EARLY, bool LATE = false>    // EARLY: the observed pixels are requested ahead of the taps (walker_kernel, below)
+                                                     // LATE: spectrum and tap pointers re-read from the kernarg segment (tile_kernel1)
 __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __restrict__ fl, int kn, int ob, int nout, int p0, int w,
                                            int tid, double* __restrict__ out, int out_stride, double& acc) {
     const int o0 = ob + LSF_PX * tid;                                         // even
@@ -1109,6 +1133,9 @@ __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __res
     double m[LSF_PX];
 #pragma unroll
     for (int p = 0; p < LSF_PX; ++p) m[p] = 0.0;
+    const double* __restrict__ pflux = VP_LATE_FIELD(LATE, I, flux);
+    const double* __restrict__ pw = VP_LATE_FIELD(LATE, I, w);
+    const double* __restrict__ pk = VP_LATE_FIELD(LATE, I, kflip);
     // the observed spectrum and its weights for this lane's pixels: in walker_kernel requested now, so that they travel
     // while the taps are applied -- behind the loop they are a memory round trip at the very end of the wave's, and the
     // workgroup's, life (C1 at 256 walkers 16.6 -> 16.3 us); the tile launches, whose workgroups cover for each other,
@@ -1118,12 +1145,12 @@ __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __res
 #pragma unroll
         for (int p = 0; p < LSF_PX; ++p) {
             const int px = min(p0 + o0 + p, I.P - 1);
-            fobs[p] = I.flux[px]; wobs[p] = I.w[px];
+            fobs[p] = pflux[px]; wobs[p] = pw[px];
         }
     }
     constexpr int NW = (8 + LSF_PX - 1 + 1) / 2;                              // 16-byte reads per group of 8 taps
     for (int j = 0; j < kn; j += 8) {
-        rec_t kb = as_rec(I.kflip) + j;                       // uniform address: scalar loads, SGPR operands of the FMAs
+        rec_t kb = as_rec(pk) + j;                       // uniform address: scalar loads, SGPR operands of the FMAs
         double f[2 * NW];
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
@@ -1142,8 +1169,8 @@ __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __res
         const int px = p0 + o0 + p;
         if (o0 + p < nout) {
             if (OUT == 0) {
-                const double d = (EARLY ? fobs[p] : I.flux[px]) - m[p];
-                acc = __builtin_fma(d * d, EARLY ? wobs[p] : I.w[px], acc);     // (flux-model)^2 * inv_sigma2
+                const double d = (EARLY ? fobs[p] : pflux[px]) - m[p];
+                acc = __builtin_fma(d * d, EARLY ? wobs[p] : pw[px], acc);     // (flux-model)^2 * inv_sigma2
             } else {
                 out[(size_t)w * out_stride + px] = m[p];
             }
@@ -1170,16 +1197,19 @@ __device__ __forceinline__ int next_near_line(unsigned long long nearm, int from
 //   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | exp table | per-chunk "line core" masks
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
 // fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
-template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false, bool FF = false>
+template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false, bool FF = false, bool W1 = false>
 __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
                                             int tid, int nthreads, const TilePre& pre, bool first,
                                             double* __restrict__ out, int out_stride VP_STAMP_ARG, bool daw_ready = false,
                                             int tix = 0) {
     const int n_eval = nout + I.K - 1;
     const int q0 = p0 - I.halo_lo;
-    const int lane = SOLO ? tid : (tid & 63);                                  // SOLO: tid IS the lane
-    const int wid = SOLO ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, and the compiler knows it
-    const int TILE_THREADS = SOLO ? 64 : nthreads, nwaves = SOLO ? 1 : (nthreads >> 6);
+    // ONE: the tile's threads are ONE wave, known at compile time -- SOLO (a wave of walker_kernel) or W1 (tile_kernel1: the
+    // single-wave workgroups of the tile launches): no wave index, no workgroup barriers, fewer scalars to keep
+    constexpr bool ONE = SOLO || W1;
+    const int lane = ONE ? tid : (tid & 63);                                   // ONE: tid IS the lane
+    const int wid = ONE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform, and the compiler knows it
+    const int TILE_THREADS = ONE ? 64 : nthreads, nwaves = ONE ? 1 : (nthreads >> 6);
     double* __restrict__ daw = fl + I.span + FL_PAD + 4;   // Dawson table for the line cores (16-B aligned)
     const int Kp = (I.K + 7) & ~7;                     // taps are zero-padded to whole groups of 8 (in HBM, host side)
     double* __restrict__ etab = daw + DAW_LDS_DOUBLES; // 2^(j/64) for the table-driven exp
@@ -1192,7 +1222,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     // A pass used to be long enough for that never to matter; with the far-field expansions a pass over a block
     // without near lines is ~60 instructions, and a wave could read the table before it was there (C3's 4-wave
     // instrument: one wrong walker in ~1000 launches, caught by the full-size test's repeat check).
-    if (!SOLO && nwaves > 1) __syncthreads();
+    if (!ONE && nwaves > 1) __syncthreads();
 
     // ---- phase A: optical depth of every line that is >= 8 Doppler widths away from the chunk.
     //      Each wave owns 3 x 64 consecutive evaluated pixels per pass (RB chunks); lines are the
@@ -1210,8 +1240,8 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             for (int r = 0; r < RB; ++r) {
                 const int i = min(base + r * 64 + lane, n_eval - 1);
                 const int q = min(max(q0 + i, 0), I.P - 1);   // edge replication = evaluate the clamped pixel
-                g[r] = I.ginv[q];
-                wv[r] = I.wave[q];
+                g[r] = VP_LATE_FIELD(W1, I, ginv)[q];
+                wv[r] = VP_LATE_FIELD(W1, I, wave)[q];
                 tau[r] = 0.0;
             }
         }
@@ -1220,7 +1250,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
         for (int r = 0; r < RB; ++r) pending[r] = false;
         // FF: this pass's block of the walker's far-field expansions (tile tix, block base / (64 RB))
         const int fblk = FF ? tix * I.ff_nblk + base / (64 * RB) : 0;
-        rec_t ffr = FF ? as_rec(I.ff + ((size_t)w * (I.ntiles * I.ff_nblk) + fblk) * FF_STRIDE) : (rec_t)0;
+        rec_t ffr = FF ? as_rec(VP_LATE_FIELD(W1, I, ff) + ((size_t)w * (I.ntiles * I.ff_nblk) + fblk) * FF_STRIDE) : (rec_t)0;
         if (METHOD == 0) {
             for (int l0 = 0; l0 < I.L; l0 += 64) {
                 unsigned long long todo[RB];
@@ -1333,7 +1363,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             }
 #undef VP_NEXT_LINE
             if (FF) {      // all the far lines of this block at once: FF_NC FMAs per pixel
-                rec_t tb = as_rec(I.ff_tab) + 4 * fblk;
+                rec_t tb = as_rec(VP_LATE_FIELD(W1, I, ff_tab)) + 4 * fblk;
                 const double ihw = tb[2], gci = tb[3];
                 double t[RB], pa[RB];
                 const double ctop = ffr[FF_NC - 1];
@@ -1392,7 +1422,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             if (i < n_eval) fl[i] = (pending[r] || tau[r] != tau[r]) ? tau[r] : exp_neg_tab(tau[r], etab);
         }
     }
-    tile_sync<SOLO>();
+    tile_sync<ONE>();
     VP_STAMP(2);
 
     // ---- phase B: line cores.  The flagged chunks of the tile are dealt round-robin to the
@@ -1421,12 +1451,12 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                 // a wave with line cores has about twice the work of one without: it goes first on its SIMD from here on
                 // (walker_kernel: the workgroup's critical path; single-wave tile workgroups: longest jobs first,
                 // C1 at 1024 walkers 44.6 -> 43.0 us, neutral at 8192 and on C2-C4)
-                if (SOLO || nwaves == 1) __builtin_amdgcn_s_setprio(2);
+                if (ONE || nwaves == 1) __builtin_amdgcn_s_setprio(2);
 #endif
                 dawson_to_lds(daw, tid, TILE_THREADS);
                 if (SOLO && tid == 0) I.core_hint[p0 / I.TP] = 1;      // (walker_kernel: next time, ahead of the records)
             }
-            tile_sync<SOLO>();
+            tile_sync<ONE>();
             VP_STAMP(6);
             int kth = 0;
             int hc0 = 0, hc1 = 0, nheld = 0;         // PAIR: flagged chunks waiting for partners (scalars, not an indexed array)
@@ -1461,7 +1491,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                 }
             }
         }
-        tile_sync<SOLO>();
+        tile_sync<ONE>();
     }
     VP_STAMP(3);
 
@@ -1490,7 +1520,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             lsf_block<1, OUT>(I, fl, Kp, ob, nout, p0, w, tid, TILE_THREADS, out, out_stride, acc);
 #else
         for (int ob = 0; ob < nout; ob += LSF_PX * TILE_THREADS)
-            lsf_block6<OUT, SOLO>(I, fl, Kp, ob, nout, p0, w, tid, out, out_stride, acc);
+            lsf_block6<OUT, SOLO, W1>(I, fl, Kp, ob, nout, p0, w, tid, out, out_stride, acc);
 #endif
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
@@ -1572,6 +1602,49 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(Ins
             for (int k = 1; k < nwaves; ++k) tile_sum += red[k];
             publish_partial(F, out, out_stride, w, out_offset + t, tile_sum);
         }
+    }
+}
+
+// tile_kernel for the common case, compiled on its own: single-wave tile workgroups (LSFs of up to 33 taps), chi^2 partial
+// (OUT = 0), fast instance.  The general kernel carries the wave index, the workgroup size and the cross-wave barriers of its
+// 2- and 4-wave forms as run-time scalars; here they are constants (tile_work<..., W1 = true>), which is worth SGPRs in a
+// kernel that spills them to VGPR lanes (every spill and reload is a VALU instruction).  Same arithmetic, same order: results
+// are bit-identical to tile_kernel's.
+//
+// Arguments that are only needed when the tile is done (where its partial sum goes, the final reduction) are NOT taken from
+// the by-value parameters: kernel arguments are loaded at entry and the ~16 scalars would sit in SGPRs -- or rather be
+// spilled and reloaded -- through the whole tile.  late_kernarg reads them from the kernarg segment at the point of use
+// (scalar loads: no VALU slot); the empty asm keeps the compiler from moving the load up.
+struct TileTail {              // what a finished tile needs (kernel argument of tile_kernel1, read late)
+    double* out;               // (W, stride) partial sums
+    int out_stride, out_offset;
+    FinalizeArgs F;
+};
+struct Tile1Args {             // the kernarg segment of tile_kernel1, as one struct (offsets by offsetof; InstDev FIRST: VP_LATE_FIELD)
+    InstDev I;
+    const double* lc;
+    const int* flags;
+    const int* genflag;
+    TileTail tail;
+};
+static_assert(offsetof(Tile1Args, I) == 0, "VP_LATE_FIELD reads InstDev at offset 0 of the kernarg segment");
+template <int METHOD, bool FF>
+__global__ __launch_bounds__(64, VP_TILE_WPE) void tile_kernel1(Tile1Args A) {
+    extern __shared__ double fl[];
+    const InstDev& I = A.I;
+    const int ot = I.core_hint[TILE_ORDER_AT + blockIdx.y];
+    const int t = ot > 0 ? ot - 1 : (int)blockIdx.y, w = blockIdx.x;
+    const int oob = A.flags[w];
+    const int gen = A.genflag ? A.genflag[w] : 0;
+    const int p0 = t * I.TP, nout = min(p0 + I.TP, I.P) - p0;
+    const TilePre pre = tile_preload(I, p0, nout, threadIdx.x);
+    if (oob || gen != 0) return;        // out-of-bounds walker: not evaluated; flagged walker: the generic launch owns it
+    rec_t lcw = as_rec(A.lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE);
+    const double wsum = wave_sum(tile_work<METHOD, 0, false, false, true, false, FF, true>(I, lcw, fl, p0, nout, w, threadIdx.x, 64, pre, true, nullptr,
+                                                                                           0 VP_STAMP_NONE, false, t));
+    if (threadIdx.x == 0) {
+        const TileTail T = late_kernarg<TileTail>(offsetof(Tile1Args, tail));
+        publish_partial(T.F, T.out, T.out_stride, w, T.out_offset + t, wsum);
     }
 }
 

@@ -301,3 +301,52 @@ def test_multi_context_errors_on_a_fresh_object_leave_the_output_alone():
         assert m._lib.vp_num_instruments(c1) == n0
         with engine_from_fixture(z) as one:
             np.testing.assert_array_equal(m.lnprob(th), one.lnprob(th))
+
+
+@pytest.mark.parametrize("structure", ["walker", "tiles-ticket", "tiles-finalize"])
+def test_host_entry_completion_modes_agree(structure):
+    """vp_lnprob_batch learns that its batch is done in one of three ways (host_spin 0: hipStreamSynchronize, 1: a completion
+    word the stream writes, 2: polling the output rows, which are pre-set to a NaN pattern no arithmetic produces and are each
+    written once).  All three return the same bits -- finite rows, -inf rows (out of bounds: written by the launch that
+    applies the prior), NaN rows (a NaN parameter) --, in every launch structure, also when the batch is re-submitted many
+    times, and an input that CARRIES the pattern (as theta, or as a flux pixel) falls back instead of hanging or lying."""
+    import struct
+    import rbvfit_amd
+    z = load_golden("c0_mgii")
+    th = np.tile(z["thetas"], (4, 1))[:100].copy()
+    th[3, 0] = z["lb"][0] - 1.0                       # -inf
+    th[17, 4] = z["ub"][4] + 5.0
+    th[40, 2] = np.nan                                # NaN propagates (SURVEY T7)
+    sentinel = struct.unpack("<d", struct.pack("<Q", 0x7FF8A5C3965A3C69))[0]
+    res = {}
+    for spin in (0, 1, 2):
+        with engine_from_fixture(z) as eng:
+            eng.set_option("host_spin", spin)
+            if structure == "walker":
+                eng.set_option("walker", 1)
+            else:
+                eng.set_option("walker", 0)
+                eng.set_option("finalize", 1 if structure == "tiles-ticket" else 0)
+            a = eng.lnprob(th)
+            for _ in range(50):
+                assert np.array_equal(eng.lnprob(th), a, equal_nan=True)
+            one = np.array([eng.lnprob(th[i])[0] for i in (0, 3, 40, 99)])
+            assert np.array_equal(one, a[[0, 3, 40, 99]], equal_nan=True)
+            th2 = th.copy(); th2[40, 2] = sentinel        # a NaN with the pattern's payload: same class of result, by the fallback
+            b = eng.lnprob(th2)
+            assert np.array_equal(np.isnan(b), np.isnan(a)) and np.array_equal(b[~np.isnan(b)], a[~np.isnan(a)])
+            res[spin] = a
+    assert np.isneginf(res[2][3]) and np.isneginf(res[2][17]) and np.isnan(res[2][40])
+    assert np.array_equal(res[0], res[1], equal_nan=True) and np.array_equal(res[0], res[2], equal_nan=True)
+    fin = np.isfinite(res[2])
+    ref = np.tile(z["lnprob"], 4)[:100]
+    np.testing.assert_allclose(res[2][fin], ref[fin], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    # the pattern inside the spectrum (every row NaN): the context notices when the instrument is added and never polls rows
+    g = lambda k: z[f"{fixture_instruments(z)[0]}__{k}"]
+    flux = g("flux").copy(); flux[7] = sentinel
+    with rbvfit_amd.Engine(0) as eng:
+        eng.set_bounds(z["lb"], z["ub"])
+        eng.add_instrument(g("wave"), flux, g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"), g("f"), g("zfac"),
+                           g("N_idx"), g("b_idx"), g("v_idx"), taps=g("taps"), lsf_mode=int(g("lsf_mode")), voigt_method=int(g("voigt_method")))
+        c = eng.lnprob(th)
+    assert np.array_equal(np.isneginf(c), np.isneginf(res[2])) and np.all(np.isnan(c[~np.isneginf(c)]))
