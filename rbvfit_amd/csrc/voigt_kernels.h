@@ -1856,6 +1856,15 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(thv) : "memory");
     VP_STAMP(9);
 #endif
+    // (wave-uniform) which instrument this wave's tile belongs to
+    const int ki = (NI > 1 && wid >= tb.t[0]) ? ((NI > 2 && wid >= tb.t[1]) ? ((NI > 3 && wid >= tb.t[2]) ? 3 : 2) : 1) : 0;
+    const InstDev& I = ki == 0 ? I0 : (ki == 1 ? I1 : (ki == 2 ? I2 : I3));
+    const int lt = ki == 0 ? wid : wid - tb.t[ki - 1];            // tile of its instrument
+    const int p0 = lt * I.TP, nout = min(p0 + I.TP, I.P) - p0;
+    // the tile's hint ("met line cores before": stage the Dawson table while waiting for the records) is asked for ahead of
+    // the wave's pixel loads: memory operations return in order, and a wave that waits for its hint behind its pixels
+    // waits for those too -- in front of the workgroup's barrier
+    const int hint_v = METHOD == 0 ? I.core_hint[lt] : 0;
     const int ngrp = (T.L + 3) >> 2, ncl = CLUSTERS ? ((T.NCm + 63) >> 6) : 0;
     const int ntask = 1 + ngrp + ncl;              // task 0: box prior; then line groups; then cluster records
     for (int task = wid; task < ntask; task += nw) {
@@ -1870,19 +1879,17 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             if (k < T.NCm) prep_cluster(A.theta + (size_t)w * A.D, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
         }
     }
-    // (wave-uniform) which instrument this wave's tile belongs to
-    const int ki = (NI > 1 && wid >= tb.t[0]) ? ((NI > 2 && wid >= tb.t[1]) ? ((NI > 3 && wid >= tb.t[2]) ? 3 : 2) : 1) : 0;
-    const InstDev& I = ki == 0 ? I0 : (ki == 1 ? I1 : (ki == 2 ? I2 : I3));
-    const int lt = ki == 0 ? wid : wid - tb.t[ki - 1];            // tile of its instrument
-    const int p0 = lt * I.TP, nout = min(p0 + I.TP, I.P) - p0;
     VP_STAMP(10);
+    // only the waves that stored records drain (s_waitcnt vmcnt(0): the write-through L1 has handed the stores to L2), and
+    // before they ask for their own pixels -- the other waves' loads stay in flight across the barrier (256 walkers 16.05 ->
+    // 15.9 us, 512 unchanged: there the record wave itself is the last to arrive)
+    if (wid < ntask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
     if (lane < EXP_LDS_DOUBLES) fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = exp2_eighth(lane);   // the wave's exp table,
                                                                            // staged while it waits for the records anyway
     // ... and the Dawson table where the tile met line cores before (1.2 us between phase A and phase B otherwise)
-    const bool daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(I.core_hint[lt]) != 0;
+    const bool daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(hint_v) != 0;
     if (daw_ready) dawson_to_lds(fl + I.span + FL_PAD + 4, lane, 64);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VP_STAMP(11);
     __syncthreads();
     VP_STAMP(1);
