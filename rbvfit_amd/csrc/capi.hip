@@ -73,6 +73,9 @@ struct Tuning {
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
     int flux_farfield = -1;     // vp_model_flux_batch[_device]: far lines from the blocks' expansions as in the lnprob launches: -1 by batch
                                 // size (the lnprob rule), 0 never, 1 whenever the instrument has the tables
+    int stretch_overlap = -1;   // vp_stretch_run, half-steps as one launch each: -1 consecutive half-steps on two streams, ordered walker by
+                                // walker through version words (StretchArgs::ovl), where two half-ensembles fit the CUs at once; 0 never
+                                // (every half-step behind the one before, one stream); 1 whenever the half-steps are one launch each
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
                                 // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
@@ -88,7 +91,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
     VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
-    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0),
+    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -135,6 +138,9 @@ struct Instrument {
 struct vp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // vp_stretch_run's overlapped half-steps: the odd half-steps (made on first use)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int num_cus = 0;
     mutable std::mutex mu;
     mutable std::string err;
     Tuning tune;
@@ -525,8 +531,12 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
 
 // One stretch-move half-step of the active half (nS walkers) as ONE launch: proposal, lnprob and accept/reject inside
 // each walker's workgroup (walker_kernel<.., SAMPLER = true>).
-void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStream_t s) {
-    const vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc, nullptr, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double))};
+// (lc_row0: first row of the record workspace this launch may use -- two half-steps in flight at once, vp_stretch_run's
+//  overlapped form, must not share rows)
+void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStream_t s, int lc_row0 = 0) {
+    const size_t nrec = (size_t)(c->inst[0].dev.L + c->inst[0].dev.NCm) * vp::LC_STRIDE;
+    const vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc + (size_t)lc_row0 * nrec, nullptr, c->inst[0].sum_logw, c->D,
+                           (int)(walker_wave_lds(c) / sizeof(double))};
     launch_walker_any<true>(c, nS, a, st, s);
 }
 
@@ -840,6 +850,9 @@ int vp_ctx_destroy(vp_ctx* c) {
     if (c->h_done) hipHostFree(c->h_done);
     gather_release(c);
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VP_OK;
@@ -1566,22 +1579,26 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     if ((rc = ensure_workspace(c, W))) return rc;
     hipStream_t s = c->stream;
     const int half = W / 2;
-    // device state: pos (W,D) | lp (W) | prop (half,D) | lp_new (half) | zz (half) | nacc (W) | nanflag | chain chunk
-    const size_t nd_state = (size_t)W * D + W + (size_t)half * D + 2 * (size_t)half;
+    // device state: pos (W,D) | lp (W) | prop (half,D) | lp_new (half) | zz (half) | second buffer of pos, lp (overlapped half-steps) |
+    //               chain chunk | nacc (W) | nanflag, timeout | versions (W)
+    const size_t nd_state = (size_t)W * D + W + (size_t)half * D + 2 * (size_t)half + (size_t)W * D + W;
     const size_t row = (size_t)W * (D + 1);                       // doubles stored per step
     size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
-    const size_t bytes = (nd_state + chunk * row) * sizeof(double) + (size_t)W * sizeof(long long) + 64;
+    const size_t bytes = (nd_state + chunk * row) * sizeof(double) + (size_t)W * sizeof(long long) + 64 + (size_t)W * sizeof(int);
     if ((rc = ensure_scratch(c, bytes))) return rc;
     double* d_pos = c->d_scratch;
     double* d_lp = d_pos + (size_t)W * D;
     double* d_prop = d_lp + W;
     double* d_lpnew = d_prop + (size_t)half * D;
     double* d_zz = d_lpnew + half;
-    double* d_chain = d_zz + half;                                // chunk * (W*D) then chunk * W
+    double* d_pos1 = d_zz + half;                                 // the rows' second buffer (overlapped half-steps)
+    double* d_lp1 = d_pos1 + (size_t)W * D;
+    double* d_chain = d_lp1 + W;                                  // chunk * (W*D) then chunk * W
     long long* d_nacc = reinterpret_cast<long long*>(d_chain + chunk * row);
-    int* d_nan = reinterpret_cast<int*>(d_nacc + W);
+    int* d_nan = reinterpret_cast<int*>(d_nacc + W);             // [0] NaN flag, [1] a device-side wait gave up
+    int* d_ver = d_nan + 16;                                      // (W) versions
     HIP_TRY(c, hipMemcpyAsync(d_pos, pos, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemsetAsync(d_nacc, 0, (size_t)W * sizeof(long long) + sizeof(int), s));
+    HIP_TRY(c, hipMemsetAsync(d_nacc, 0, (size_t)W * sizeof(long long) + 64 + (size_t)W * sizeof(int), s));
     if (have_lnprob) {
         for (int w = 0; w < W; ++w)
             if (lnprob[w] != lnprob[w]) return fail(c, VP_ENAN, "vp_stretch_run: the initial lnprob holds NaN (Probability function returned NaN)");
@@ -1603,6 +1620,29 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     const bool fuse = W <= 1024 && !c->tune.no_fused_accept;   // accept + next proposal in one launch
     const int wthr = ((W + 63) / 64) * 64;
     bool have_prop = false;                                   // is the proposal of the coming pass already enqueued?
+    // Overlapped half-steps: consecutive half-steps on two streams, each walker waiting for its partner's version word only
+    // (StretchArgs::ovl).  Both launches must be able to sit on the CUs together -- a workgroup that waits holds its slot, and
+    // the one it waits for must never be left without one: two half-ensembles of workgroups within what the CUs hold at once.
+    bool ovl = false;
+    if (one_launch && c->tune.stretch_overlap != 0 && nsteps > 0) {
+        if (c->num_cus == 0) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) c->num_cus = n;
+        }
+        const int nt = walker_tiles(c);
+        const long per_cu = std::max(1, std::min(24 / std::max(1, nt), (int)(c->lds_limit / walker_lds_bytes(c))));
+        ovl = c->tune.stretch_overlap > 0 || (per_cu >= 2 && 2l * half <= per_cu * (long)c->num_cus);
+        if (ovl && !c->stream2) {
+            if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ovl = false; }
+        }
+    }
+    hipStream_t s2 = ovl ? c->stream2 : s;
+    if (ovl) {      // what the first stream has set up (rows, versions) before the second one's first launch
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    }
     for (int done = 0; done < nsteps;) {
         const int n = chain ? (int)std::min<size_t>(chunk, (size_t)(nsteps - done)) : nsteps - done;
         for (int it = 0; it < n; ++it) {
@@ -1615,7 +1655,20 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
                     sa.chain_pos = chain ? d_chain + (size_t)it * W * D : (double*)nullptr;
                     sa.chain_lp = chain ? d_chain + chunk * (size_t)W * D + (size_t)it * W : (double*)nullptr;
                     sa.a = a; sa.seed = seed; sa.step = step; sa.s0 = s0; sa.c0 = c0; sa.nC = half; sa.half = h;
-                    launch_walker_stretch(c, half, sa, s);
+                    if (ovl) {
+                        // every walker has been updated k = done + it times when this step begins (the first half once more when
+                        // h = 1): rows live in buffer (update count) & 1
+                        const int k = done + it, t = 2 * k + h;
+                        double* pb[2] = {d_pos, d_pos1};
+                        double* lb2[2] = {d_lp, d_lp1};
+                        sa.ovl = 1; sa.need = t; sa.mine = t + 1; sa.ver = d_ver; sa.timeout = d_nan + 1;
+                        sa.pos_x = pb[k & 1]; sa.lp_x = lb2[k & 1];
+                        sa.pos_w = pb[(k + 1) & 1]; sa.lp_w = lb2[(k + 1) & 1];
+                        sa.pos_c = pb[(h ? k + 1 : k) & 1];
+                        launch_walker_stretch(c, half, sa, h ? s2 : s, h ? half : 0);
+                    } else {
+                        launch_walker_stretch(c, half, sa, s);
+                    }
                     continue;
                 }
                 if (!have_prop)
@@ -1641,23 +1694,29 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
             }
         }
         HIP_TRY(c, hipGetLastError());
+        if (ovl) {      // the second stream's half-steps of this chunk are done before the first stream copies anything out
+            HIP_TRY(c, hipEventRecord(c->ev_join, s2));
+            HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        }
         if (chain) {
             HIP_TRY(c, hipMemcpyAsync(chain + (size_t)done * W * D, d_chain, (size_t)n * W * D * sizeof(double), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipMemcpyAsync(chain_lnprob + (size_t)done * W, d_chain + chunk * (size_t)W * D, (size_t)n * W * sizeof(double),
                                       hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, hipStreamSynchronize(s));      // (the host waits: the next chunk's launches are enqueued behind the copies)
         }
         done += n;
     }
     std::vector<long long> h_nacc(W);
-    int h_nan = 0;
-    HIP_TRY(c, hipMemcpyAsync(pos, d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(lnprob, d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
+    int h_flags[2] = {0, 0};
+    // (overlapped half-steps: after nsteps updates the rows are in buffer nsteps & 1)
+    HIP_TRY(c, hipMemcpyAsync(pos, (ovl && (nsteps & 1)) ? d_pos1 : d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(lnprob, (ovl && (nsteps & 1)) ? d_lp1 : d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(h_nacc.data(), d_nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(&h_nan, d_nan, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(h_flags, d_nan, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (h_flags[1]) return fail(c, VP_EHIP, "vp_stretch_run: a workgroup's wait for its partner's half-step gave up (overlapped half-steps)");
     if (naccepted) for (int w = 0; w < W; ++w) naccepted[w] += (int64_t)h_nacc[w];
-    if (h_nan) return fail(c, VP_ENAN, "vp_stretch_run: Probability function returned NaN");
+    if (h_flags[0]) return fail(c, VP_ENAN, "vp_stretch_run: Probability function returned NaN");
     return VP_OK;
 }
 

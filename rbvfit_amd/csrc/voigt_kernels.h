@@ -1746,6 +1746,18 @@ struct StretchArgs {
     int s0, c0, nC, half;  // active rows [s0, s0 + gridDim.x), complementary rows [c0, c0 + nC)
     Replicas rep;          // rep.n > 0 (vp_multi_stretch_run): moved rows are written to every replica of the ensemble
                            // (this context's own among them) instead of pos / lp alone
+    // Overlapped half-steps (ovl != 0, vp_stretch_run): the launches of consecutive half-steps are on two streams and run side
+    // by side; a walker's workgroup waits for ITS partner alone -- ver[c0 + j] >= need, the partner's workgroup of the half-step
+    // before publishes `mine` behind its row -- instead of the whole launch before it.  Everything a workgroup does before it
+    // needs theta (kernel arguments, pixel loads, table staging) then runs under the previous half-step's arithmetic, and no
+    // kernel boundary lies on the chain of dependent half-steps.  Rows are double-buffered by the parity of the walker's update
+    // count, so that a late reader of the half-step before never meets this half-step's store: own row read from pos_x / lp_x,
+    // partner from pos_c, the row of this half-step (moved or not) written to pos_w / lp_w.  `timeout`: a wait gave up.
+    int ovl, need, mine;
+    int* ver;              // (W)
+    const double* pos_c; const double* pos_x; double* pos_w;
+    const double* lp_x; double* lp_w;
+    int* timeout;
 };
 
 struct WalkerArgs {
@@ -1832,13 +1844,34 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         int j = (int)(u01(r.v[2], r.v[3]) * (double)S.nC);
         j = j < S.nC - 1 ? j : S.nC - 1;
         const int d = min(lane, A.D - 1);
-        const double x = S.pos[(size_t)(S.s0 + w) * A.D + d], c = S.pos[(size_t)(S.c0 + j) * A.D + d];
+        const double* __restrict__ posX = S.ovl ? S.pos_x : S.pos;
+        const double* __restrict__ lpX = S.ovl ? S.lp_x : S.lp;
+        double x = 0.0, c = 0.0;
+        // (overlapped half-steps: only the waves that use the proposal before the workgroup's barrier -- prior, records, the
+        //  accept step's operands -- wait for the partner; the others go on to their pixels and tables)
+        const bool uses_theta = !S.ovl || wid < 1 + ((T.L + 3) >> 2) + (CLUSTERS ? ((T.NCm + 63) >> 6) : 0) || wid == nw - 1;
+        if (uses_theta) {
+            x = posX[(size_t)(S.s0 + w) * A.D + d];
+            if (S.ovl) {
+                int spins = 0;
+                while (__hip_atomic_load(S.ver + S.c0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S.need) {
+                    if (++spins > SYNC_SPIN_LIMIT) {
+                        if (lane == 0) __hip_atomic_store(S.timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                c = __hip_atomic_load(S.pos_c + (size_t)(S.c0 + j) * A.D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                c = S.pos[(size_t)(S.c0 + j) * A.D + d];
+            }
+        }
         thv = c - (c - x) * z;
         // everything the accept / reject step needs besides the proposal's lnprob, by the last wave while it would wait for
         // the records anyway: at the end of the workgroup's life it was ~2.5 us of Philox blocks, logarithms and a memory round
         // trip on wave 0 alone
         if (wid == nw - 1) {
-            const double lp_old = S.lp[S.s0 + w];
+            const double lp_old = lpX[S.s0 + w];
             const Philox4 r1 = draw(S.seed, S.step, S.half, S.s0 + w, 1u);
             const double lz = (double)(A.D - 1) * log(z), lu = log(u01(r1.v[0], r1.v[1]));
             if (lane == 0) { stash[0] = lz; stash[1] = lu; stash[2] = lp_old; }
@@ -1944,7 +1977,18 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             const double lnq = stash[0] + lnp - lp_old;
             accept = stash[1] < lnq;
         }
-        if (accept) {
+        if (S.ovl) {
+            // this half-step's row -- moved or not -- into the buffer the next half-steps read, then the walker's version:
+            // agent-scope stores, drained before the version (the partner polls it with agent-scope loads and reads the row
+            // the same way)
+            if (lane < A.D) __hip_atomic_store(S.pos_w + (size_t)ws * A.D + lane, accept ? y : x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                __hip_atomic_store(S.lp_w + ws, accept ? lnp : lp_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (accept) atomicAdd(reinterpret_cast<unsigned long long*>(S.nacc + ws), 1ull);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(S.ver + ws, S.mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (accept) {
             if (S.rep.n > 0) {
                 for (int rr = 0; rr < S.rep.n; ++rr) {
                     if (lane < A.D) S.rep.pos[rr][(size_t)ws * A.D + lane] = y;

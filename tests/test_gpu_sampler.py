@@ -58,6 +58,34 @@ def test_runs_are_reproducible_and_splittable():
     np.testing.assert_array_equal(nochain[0], a[0])
 
 
+@pytest.mark.parametrize("W,pixels,nsteps", [(48, 512, 31), (512, 4096, 12), (6, 300, 40)])
+def test_overlapped_half_steps_do_not_show_in_the_chain(W, pixels, nsteps):
+    """vp_stretch_run puts consecutive half-steps on two streams and lets every walker's workgroup wait for ITS partner's
+    version word instead of the whole launch before (StretchArgs::ovl; rows double-buffered by update count).  Forced on,
+    forced off and the automatic choice give the same chain, stored lnprob, final state and acceptance counts, bit for
+    bit -- with odd and even step counts (the final rows live in either buffer), split runs, chain chunks, and when a
+    proposal's lnprob is NaN the error is the same."""
+    wl = _workload(W, pixels)
+    eng, p0 = wl.engine, wl.thetas
+    runs = {}
+    for mode in (0, 1, -1):
+        eng.set_option("stretch_overlap", mode)
+        a = eng.stretch_run(p0, nsteps, seed=5)
+        h1 = eng.stretch_run(p0, nsteps // 2, seed=5)
+        h2 = eng.stretch_run(h1[0], nsteps - nsteps // 2, lnprob=h1[1], seed=5, step0=nsteps // 2, naccepted=h1[4])
+        np.testing.assert_array_equal(np.concatenate([h1[2], h2[2]]), a[2])
+        np.testing.assert_array_equal(h2[0], a[0]); np.testing.assert_array_equal(h2[4], a[4])
+        nochain = eng.stretch_run(p0, nsteps, seed=5, store_chain=False)
+        np.testing.assert_array_equal(nochain[0], a[0]); np.testing.assert_array_equal(nochain[1], a[1])
+        runs[mode] = a
+    for mode in (1, -1):
+        for k in (0, 1, 2, 3, 4):
+            np.testing.assert_array_equal(runs[mode][k], runs[0][k])
+    np.testing.assert_array_equal(runs[0][0], runs[0][2][-1])
+    eng.set_option("stretch_overlap", -1)
+    wl.engine.close()
+
+
 def test_sampled_distribution_agrees_with_the_host_sampler():
     from rbvfit_amd.sampler import DeviceStretchSampler, StretchMoveSampler
     wl = _workload()
