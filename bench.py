@@ -660,7 +660,7 @@ def rank_main(args):
             # the walker loop itself on the GPU (vp_stretch_run): real ensemble steps per second, two
             # half-ensemble passes per step, proposals and accept/reject in HBM -- not part of `value`
             if W % 2 == 0:
-                nst = 300 if args.config in ("C0", "C1") else 20
+                nst = 3000 if args.config in ("C0", "C1") else (200 if args.config in ("C2", "C3") else 60)
                 wl.engine.stretch_run(wl.thetas, max(2, nst // 15), seed=1, store_chain=False)
                 ts0 = time.perf_counter()
                 wl.engine.stretch_run(wl.thetas, nst, seed=1, store_chain=False)
@@ -744,7 +744,9 @@ def rank_main(args):
             "passes_per_sec": args.steps / elapsed,
             "mcmc_steps_per_sec": sampler_steps,
             "mcmc_steps_per_sec_note": "device-resident stretch move (vp_stretch_run): one ensemble step = two half-ensemble "
-                                       "lnprob passes + propose/accept kernels; rank 0's walkers",
+                                       "launches (proposal, lnprob, accept / reject inside each walker's workgroup; consecutive half-steps "
+                                       "overlap on two streams, every walker waiting for its partner's row only); rank 0's walkers; wall "
+                                       "time around the call, upload of the start positions and download of the final state included",
             "slice_sampler": slice_info,
             "slice_sampler_note": "device-resident ensemble slice sampling (vp_slice_run, zeus' differential move): ensemble steps/s, "
                                   "lnprob evaluations per walker and step, and the evaluations/s they amount to",
