@@ -90,7 +90,11 @@ int vp_update_spectrum(vp_ctx* ctx, int inst, const double* flux, const double* 
                        const double* log_inv_sigma2);
 
 /* lnprob for a batch of walkers.  Replaces: map(vfit.lnprob, theta_rows) (vfit_mcmc.py:348-353,
- * the sampler fan-out of :408-440).  theta is row-major (W, D) host memory, out is (W,). */
+ * the sampler fan-out of :408-440).  theta is row-major (W, D) host memory, out is (W,).
+ * Batches of up to 1 MiB of theta are read / written by the kernels straight from / to a pinned staging buffer, and the call
+ * returns as soon as every output row has arrived there (the rows are pre-set to a NaN bit pattern that no arithmetic produces and
+ * each is written exactly once; inputs carrying that payload make the call wait on a stream-written completion word instead):
+ * `out` is complete and the context idle-equivalent when it returns, as with any synchronous call. */
 int vp_lnprob_batch(vp_ctx* ctx, int W, int D, const double* theta, double* out);
 
 /* Same, operands already resident on the context's GPU; enqueued on `hip_stream` (a hipStream_t,
@@ -128,7 +132,9 @@ int vp_gather_destroy(vp_ctx* ctx);
 /* Model flux for a batch.  Replaces: CompiledVoigtModel.model_flux per row
  * (core/voigt_model.py:295-311).  out is row-major (W, P) host memory.  convolved = 0 returns the
  * profile before the LSF (VoigtModel.evaluate(return_unconvolved=True), :509-558).  The prior is
- * not consulted (model_flux has none). */
+ * not consulted (model_flux has none).  Instruments with >= 8 lines take the lines far from a 192-pixel block from the block's
+ * expansion as the lnprob launches do, by the same batch-size rule (option "flux_farfield": -1 / 0 / 1; flux within the 1e-12 contract
+ * either way). */
 int vp_model_flux_batch(vp_ctx* ctx, int inst, int W, int D, const double* theta, double* out,
                         int convolved);
 int vp_model_flux_batch_device(vp_ctx* ctx, int inst, int W, int D, const double* d_theta,
@@ -157,7 +163,10 @@ int vp_voigt_h(vp_ctx* ctx, int na, const double* a, int nx, const double* x, do
  *   chain      (nsteps, W, D) host or NULL;  chain_lnprob (nsteps, W) host or NULL: state after each step.
  *   naccepted  (W) host or NULL: accepted proposals per walker, ADDED to the values passed in.
  * Returns VP_ENAN (state and outputs undefined) if a proposal's lnprob is NaN -- emcee raises
- * "Probability function returned NaN" there. */
+ * "Probability function returned NaN" there.
+ * Where a half-step is one launch and two half-ensembles of workgroups fit the GPU at once, consecutive half-steps are enqueued on
+ * two streams of the context and overlap: a walker's workgroup waits (bounded; VP_EHIP if a wait gives up) for its partner's row
+ * of the half-step before, not for that whole launch.  The chain does not depend on it (option "stretch_overlap": -1 / 0 / 1). */
 int vp_stretch_run(vp_ctx* ctx, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
                    uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted);
 
