@@ -73,6 +73,8 @@ struct Tuning {
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
     int flux_farfield = -1;     // vp_model_flux_batch[_device]: far lines from the blocks' expansions as in the lnprob launches: -1 by batch
                                 // size (the lnprob rule), 0 never, 1 whenever the instrument has the tables
+    int walker_perm = -1;       // walker_kernel deals its tiles to the waves by estimated cost (WalkerArgs::wperm): -1 for batches of at most
+                                // one workgroup per CU, 0 never (wave k takes tile k), 1 always
     int stretch_overlap = -1;   // vp_stretch_run, half-steps as one launch each: -1 consecutive half-steps on two streams, ordered walker by
                                 // walker through version words (StretchArgs::ovl), where two half-ensembles fit the CUs at once; 0 never
                                 // (every half-step behind the one before, one stream); 1 whenever the half-steps are one launch each
@@ -91,7 +93,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
     VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
-    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0),
+    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -110,6 +112,7 @@ struct Instrument {
     vp::InstDev dev_w{};         // walker_kernel's geometry: single-wave tiles of 384 evaluated pixels whatever the LSF
                                  // length (= dev for K <= 33; longer LSFs: more halo per tile, but one launch)
     size_t lds_w = 0;            // LDS bytes of one such tile; 0: the LSF is too long for single-wave tiles
+    unsigned long long wperm = 0xFEDCBA9876543210ull;   // walker_kernel (this instrument alone): tile of wave k in nibble k (WalkerArgs)
 
     vp::LinesDev lines{};
     double sum_logw = 0.0;
@@ -522,8 +525,21 @@ void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::Stre
     else hipLaunchKernelGGL((vp::walker_kernel<0, false, SAMPLER>), grid, block, lds, s, d0, t0, a, st);
 }
 
+// which deal of tiles to waves a walker launch of W workgroups gets (Tuning::walker_perm)
+unsigned long long walker_perm_for(vp_ctx* c, int W) {
+    const unsigned long long ident = 0xFEDCBA9876543210ull;
+    if (c->inst.size() != 1 || c->tune.walker_perm == 0) return ident;
+    if (c->tune.walker_perm > 0) return c->inst[0].wperm;
+    if (c->num_cus == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) c->num_cus = n;
+    }
+    return (c->num_cus > 0 && W <= c->num_cus) ? c->inst[0].wperm : ident;
+}
+
 void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s, const vp::Replicas* gather = nullptr) {
-    const vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double))};
+    const vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double)),
+                           walker_perm_for(c, W)};
     vp::StretchArgs st{};
     if (gather) st.rep = *gather;            // (the plain form's only use of the sampler arguments: where the results go)
     launch_walker_any<false>(c, W, a, st, s);
@@ -536,7 +552,7 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
 void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStream_t s, int lc_row0 = 0) {
     const size_t nrec = (size_t)(c->inst[0].dev.L + c->inst[0].dev.NCm) * vp::LC_STRIDE;
     const vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc + (size_t)lc_row0 * nrec, nullptr, c->inst[0].sum_logw, c->D,
-                           (int)(walker_wave_lds(c) / sizeof(double))};
+                           (int)(walker_wave_lds(c) / sizeof(double)), walker_perm_for(c, nS)};
     launch_walker_any<true>(c, nS, a, st, s);
 }
 
@@ -1127,6 +1143,25 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
                 for (int t = 0; t < gd->ntiles; ++t) idx[t] = t;
                 std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
                 for (int t = 0; t < gd->ntiles; ++t) tabl[vp::TILE_ORDER_AT + t] = idx[t] + 1;
+            }
+            // walker_kernel's deal of the tiles to its waves by that cost (WalkerArgs::wperm): waves k, k + 4, k + 8 of a workgroup
+            // share a SIMD, so the tiles go out in tiers of four, every other tier backwards -- each SIMD one tile of every tier --,
+            // starting behind the waves that form the records (they get the cheapest tiles).  Measured on C1, us per pass, tile
+            // order / dealt: 256 walkers 15.98 / 15.68; 512 walkers (two workgroups per CU) 21.5 / 21.9 -- there two waves with
+            // line cores that share a SIMD keep it issuing between them, so the deal is used for single-layer batches only
+            if ((gd == &in.dev_w || (gi < 2 && in.dev_w.TP == gd->TP && in.dev_w.ntiles == gd->ntiles)) && gd->ntiles <= 16) {
+                const int nw = gd->ntiles, ntask = std::min(nw, 1 + (L + 3) / 4);
+                std::vector<int> idx(nw), seq(nw);
+                for (int t = 0; t < nw; ++t) idx[t] = t;
+                if (any) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+                for (int k = 0; k < nw; ++k) seq[k] = (ntask + k) % nw;       // the waves with entry tasks come last (cheapest tiles)
+                unsigned long long perm = 0xFEDCBA9876543210ull;
+                for (int k = 0; k < nw; ++k) {
+                    const int tier = k / 4, lo = tier * 4, hi = std::min(nw, lo + 4) - 1;
+                    const int tile = idx[(tier & 1) ? hi - (k - lo) : k];
+                    perm = (perm & ~(15ull << (4 * seq[k]))) | ((unsigned long long)tile << (4 * seq[k]));
+                }
+                in.wperm = perm;
             }
             int* d_tabl;
             if ((rc = upload<int>(c, &in, tabl.data(), tabl.size(), &d_tabl))) { for (void* p : in.allocs) hipFree(p); return rc; }

@@ -1769,6 +1769,9 @@ struct WalkerArgs {
     double sum_logw;       // sum of log inv_sigma2 of the instrument
     int D;
     int wave_lds;          // LDS doubles per wave (= per tile)
+    unsigned long long wperm;   // nibble k = the tile wave k evaluates (identity: 0xFEDCBA9876543210): the host's deal of the tiles to the
+                           // waves by estimated cost (capi.hip: vp_add_instrument, walker_perm_for).  Tile sums still meet in LDS by
+                           // TILE index, so results do not depend on it
 };
 
 // Where a walker's lnprob goes (one thread per workgroup): the batch's output vector, and -- direct-write gather of a
@@ -1890,9 +1893,10 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     VP_STAMP(9);
 #endif
     // (wave-uniform) which instrument this wave's tile belongs to
-    const int ki = (NI > 1 && wid >= tb.t[0]) ? ((NI > 2 && wid >= tb.t[1]) ? ((NI > 3 && wid >= tb.t[2]) ? 3 : 2) : 1) : 0;
+    const int tw = (int)((A.wperm >> (4 * wid)) & 15ull);         // the tile (over all instruments) this wave evaluates
+    const int ki = (NI > 1 && tw >= tb.t[0]) ? ((NI > 2 && tw >= tb.t[1]) ? ((NI > 3 && tw >= tb.t[2]) ? 3 : 2) : 1) : 0;
     const InstDev& I = ki == 0 ? I0 : (ki == 1 ? I1 : (ki == 2 ? I2 : I3));
-    const int lt = ki == 0 ? wid : wid - tb.t[ki - 1];            // tile of its instrument
+    const int lt = ki == 0 ? tw : tw - tb.t[ki - 1];              // tile of its instrument
     const int p0 = lt * I.TP, nout = min(p0 + I.TP, I.P) - p0;
     // the tile's hint ("met line cores before": stage the Dawson table while waiting for the records) is asked for ahead of
     // the wave's pixel loads: memory operations return in order, and a wave that waits for its hint behind its pixels
@@ -1943,7 +1947,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
         asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
         const double wsum = wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS, daw_ready));
-        if (lane == 0) red[wid] = wsum;
+        if (lane == 0) red[tw] = wsum;
         __syncthreads();
         VP_STAMP(5);
         if (wid != 0) return;
