@@ -1674,6 +1674,9 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
         }
     }
     hipStream_t s2 = ovl ? c->stream2 : s;
+    // (whatever way this call ends -- an error return from the middle of the loop included -- nothing of it is left running on the
+    //  second stream when the context's mutex is released)
+    struct DrainSecond { hipStream_t q; bool on; ~DrainSecond() { if (on) (void)hipStreamSynchronize(q); } } drain_second{s2, ovl};
     if (ovl) {      // what the first stream has set up (rows, versions) before the second one's first launch
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
