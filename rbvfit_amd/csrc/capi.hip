@@ -73,6 +73,8 @@ struct Tuning {
     int slice_rows = 2;         // device slice sampler: rows of a round's lnprob batch per walker of the half-ensemble (2 ... 8)
     int flux_farfield = -1;     // vp_model_flux_batch[_device]: far lines from the blocks' expansions as in the lnprob launches: -1 by batch
                                 // size (the lnprob rule), 0 never, 1 whenever the instrument has the tables
+    int walker_prio = -1;       // walker_kernel: raised issue priority for the waves with line cores: -1 where workgroups share a CU, 0 never, 1 always
+    long walker_perm_hex = 0;   // (experiments) an explicit WalkerArgs::wperm
     int walker_perm = -1;       // walker_kernel deals its tiles to the waves by estimated cost (WalkerArgs::wperm): -1 for batches of at most
                                 // one workgroup per CU, 0 never (wave k takes tile k), 1 always
     int stretch_overlap = -1;   // vp_stretch_run, half-steps as one launch each: -1 consecutive half-steps on two streams, ordered walker by
@@ -93,7 +95,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
     VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
-    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0),
+    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0), VP_KNOB(walker_prio, "RBVFIT_AMD_WALKER_PRIO", 0), VP_KNOB(walker_perm_hex, "RBVFIT_AMD_WALKER_PERM_HEX", 1),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -102,7 +104,7 @@ void set_knob(Tuning& t, const Knob& k, long v) {
 Tuning tuning_from_env() {
     Tuning t;
     for (const Knob& k : g_knobs)
-        if (const char* e = getenv(k.env)) set_knob(t, k, *e ? atol(e) : 1);     // set but empty counts as 1
+        if (const char* e = getenv(k.env)) set_knob(t, k, *e ? (long)strtoull(e, nullptr, 0) : 1);     // set but empty counts as 1 (decimal, 0x.., negative)
     return t;
 }
 
@@ -529,6 +531,7 @@ void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::Stre
 unsigned long long walker_perm_for(vp_ctx* c, int W) {
     const unsigned long long ident = 0xFEDCBA9876543210ull;
     if (c->inst.size() != 1 || c->tune.walker_perm == 0) return ident;
+    if (c->tune.walker_perm_hex != 0) return (unsigned long long)c->tune.walker_perm_hex;     // (experiments: an explicit deal)
     if (c->tune.walker_perm > 0) return c->inst[0].wperm;
     if (c->num_cus == 0) {
         int n = 0;
@@ -536,10 +539,19 @@ unsigned long long walker_perm_for(vp_ctx* c, int W) {
     }
     return (c->num_cus > 0 && W <= c->num_cus) ? c->inst[0].wperm : ident;
 }
+// raised issue priority for the waves with line cores: where workgroups share a CU (WalkerArgs::prio)
+int walker_prio_for(vp_ctx* c, int W) {
+    if (c->tune.walker_prio >= 0) return c->tune.walker_prio ? 1 : 0;
+    if (c->num_cus == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) c->num_cus = n;
+    }
+    return (c->num_cus > 0 && W <= c->num_cus) ? 0 : 1;
+}
 
 void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s, const vp::Replicas* gather = nullptr) {
     const vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double)),
-                           walker_perm_for(c, W)};
+                           walker_prio_for(c, W), walker_perm_for(c, W)};
     vp::StretchArgs st{};
     if (gather) st.rep = *gather;            // (the plain form's only use of the sampler arguments: where the results go)
     launch_walker_any<false>(c, W, a, st, s);
@@ -552,7 +564,9 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
 void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStream_t s, int lc_row0 = 0) {
     const size_t nrec = (size_t)(c->inst[0].dev.L + c->inst[0].dev.NCm) * vp::LC_STRIDE;
     const vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc + (size_t)lc_row0 * nrec, nullptr, c->inst[0].sum_logw, c->D,
-                           (int)(walker_wave_lds(c) / sizeof(double)), walker_perm_for(c, nS)};
+                           (int)(walker_wave_lds(c) / sizeof(double)),
+                           (st.ovl && c->tune.walker_prio < 0) ? 1 : walker_prio_for(c, nS),     // (overlapped half-steps share the CUs)
+                           walker_perm_for(c, nS)};
     launch_walker_any<true>(c, nS, a, st, s);
 }
 

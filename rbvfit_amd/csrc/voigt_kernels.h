@@ -839,6 +839,9 @@ __device__ long long g_stamps[STAMP_W * STAMP_WAVES * STAMP_STAGES];
 #ifndef VP_TILE_WPE
 #define VP_TILE_WPE 1             // tile_kernel: waves per SIMD the register allocation must leave room for
 #endif
+#ifndef VP_PRIO_LEVEL
+#define VP_PRIO_LEVEL 2           // issue priority of a wave whose tile holds line cores (ablations: 1, 3)
+#endif
 #ifndef VP_CORE_ILP
 #define VP_CORE_ILP 2             // phase B of single-wave tiles in walker_kernel: flagged chunks evaluated side by side
 #endif
@@ -1451,7 +1454,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                 // a wave with line cores has about twice the work of one without: it goes first on its SIMD from here on
                 // (walker_kernel: the workgroup's critical path; single-wave tile workgroups: longest jobs first,
                 // C1 at 1024 walkers 44.6 -> 43.0 us, neutral at 8192 and on C2-C4)
-                if (ONE || nwaves == 1) __builtin_amdgcn_s_setprio(2);
+                if (ONE || nwaves == 1) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
 #endif
                 dawson_to_lds(daw, tid, TILE_THREADS);
                 if (SOLO && tid == 0) I.core_hint[p0 / I.TP] = 1;      // (walker_kernel: next time, ahead of the records)
@@ -1769,6 +1772,7 @@ struct WalkerArgs {
     double sum_logw;       // sum of log inv_sigma2 of the instrument
     int D;
     int wave_lds;          // LDS doubles per wave (= per tile)
+    int prio;              // != 0: the waves whose tiles hold line cores run at raised issue priority
     unsigned long long wperm;   // nibble k = the tile wave k evaluates (identity: 0xFEDCBA9876543210): the host's deal of the tiles to the
                            // waves by estimated cost (capi.hip: vp_add_instrument, walker_perm_for).  Tile sums still meet in LDS by
                            // TILE index, so results do not depend on it
@@ -1933,7 +1937,9 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
 #ifndef VP_NO_PRIO
     // the tiles with line cores are the workgroup's critical path (twice the work of the others): their waves go first
     // on their SIMDs from the start where the hint says so, from phase B on otherwise
-    if (daw_ready) __builtin_amdgcn_s_setprio(2);
+    // (only where two workgroups share the CU -- A.prio, set by the host for batches of more than one workgroup per CU: 512 walkers
+    //  24.4 us without, 21.5 with; a workgroup that has its CU to itself measured 1 % slower with it: 256 walkers 15.68 / 15.50)
+    if (daw_ready && A.prio) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
 #endif
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
     if (oobw && !SAMPLER) {
