@@ -26,7 +26,9 @@ def main():
     lib.vp_debug_read_stamps.argtypes = [C.POINTER(C.c_longlong), C.c_int]
     lib.vp_debug_read_stamps.restype = C.c_int
     for W in [int(a) for a in sys.argv[1:]] or [256, 512]:
-        wl = make_workload("C1", walkers=W)
+        PIX = int(os.environ.get("TIMELINE_PIXELS", "0")) or None      # (with RBVFIT_AMD_SPAN: other tile geometries)
+        wl = make_workload("C1", walkers=W, pixels=PIX)
+        NT = min(16, int(wl.engine._lib.vp_instrument_pixels(wl.engine._ctx, 0) and (os.environ.get("TIMELINE_TILES") or 12)))
         eng = wl.engine
         eng.set_option("walker", 1)
         for _ in range(20):
@@ -42,16 +44,16 @@ def main():
                   f"polls that found a slot not ready {cnt[2]}, helper pair items {cnt[3]}  (per walker: {cnt[0] / W:.1f}, {cnt[1] / W:.1f}, {cnt[2] / W:.1f}, {cnt[3] / W:.1f})")
         buf = np.zeros(NW * NWAVES * NST, dtype=np.int64)
         assert lib.vp_debug_read_stamps(buf.ctypes.data_as(C.POINTER(C.c_longlong)), buf.size) == 0
-        raw = buf.reshape(NW, NWAVES, NST)[:W, :12, :]
+        raw = buf.reshape(NW, NWAVES, NST)[:W, :NT, :]
         hw = raw[:, :, 7]
         simd = (hw >> 4) & 3
         cu = ((hw >> 32) & 0xF) * 64 + ((hw >> 13) & 7) * 16 + ((hw >> 8) & 0xF)     # (xcc, se, cu) as one key
         print(f"\n=== C1, {W} walkers: SIMD of wave t (share of walkers on SIMD 0..3), by tile:")
-        for t in range(12):
+        for t in range(NT):
             print(f"    {t:4d} " + " ".join(f"{np.mean(simd[:, t] == k):6.2f}" for k in range(4)))
         rel_simd = (simd - simd[:, :1]) & 3
         print("    SIMD of wave t relative to wave 0 (mode, share): " + " ".join(
-            f"{np.bincount(rel_simd[:, t], minlength=4).argmax()}:{np.bincount(rel_simd[:, t], minlength=4).max() / W:.2f}" for t in range(12)))
+            f"{np.bincount(rel_simd[:, t], minlength=4).argmax()}:{np.bincount(rel_simd[:, t], minlength=4).max() / W:.2f}" for t in range(NT)))
         print(f"    workgroups whose waves all sit on one CU: {np.mean([len(set(cu[w])) == 1 for w in range(W)]):.2f};"
               f" distinct CUs used: {len(set(cu[:, 0]))}; max workgroups on one CU: {np.bincount(np.unique(cu[:, 0], return_inverse=True)[1]).max()}")
         st = raw.astype(np.float64)
@@ -70,7 +72,7 @@ def main():
         names = ["entry", "records", "phaseA", "phaseB", "LSF", "final", "B-start", "-", "kernarg", "theta", "prepped", "drained"]
         print("    end of stage relative to the workgroup's first wave entry, us (mean over walkers), by tile:")
         print("    tile " + " ".join(f"{n:>8s}" for n in names))
-        for t in range(12):
+        for t in range(NT):
             print(f"    {t:4d} " + " ".join(f"{np.nanmean(rel[:, t, k]):8.2f}" for k in range(len(names))))
         print("    all  " + " ".join(f"{np.nanmean(rel[:, :, k]):8.2f}" for k in range(len(names))))
         print("    p90  " + " ".join(f"{np.nanpercentile(rel[:, :, k], 90):8.2f}" for k in range(len(names))))
