@@ -154,6 +154,10 @@ __device__ __forceinline__ T late_kernarg(size_t byte_offset) {
     return v;
 }
 #define VP_LATE_FIELD(LATE, I, field) ((LATE) ? late_kernarg<decltype((I).field)>(offsetof(InstDev, field)) : (I).field)
+// ... as a pointer in the GLOBAL address space: a pointer the compiler did not see come in as a kernel argument is a generic one
+// to it, and loads through it would be flat_load (counted in lgkmcnt as well as vmcnt: they stall the LDS and scalar-load waits)
+typedef const double __attribute__((address_space(1)))* gptr_t;
+#define VP_LATE_GPTR(LATE, I, field) ((gptr_t)reinterpret_cast<unsigned long long>(VP_LATE_FIELD(LATE, I, field)))
 
 // Sum over the 64 lanes of a wave, the same value in every lane.  Data-parallel-primitive moves inside the 16-lane rows
 // (lane ^ 1, lane ^ 2, 7 - lane, 15 - lane), then row 0 into row 1 and row 2 into row 3 (row_bcast:15), rows 0-1 into rows 2-3
@@ -1136,8 +1140,8 @@ __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __res
     double m[LSF_PX];
 #pragma unroll
     for (int p = 0; p < LSF_PX; ++p) m[p] = 0.0;
-    const double* __restrict__ pflux = VP_LATE_FIELD(LATE, I, flux);
-    const double* __restrict__ pw = VP_LATE_FIELD(LATE, I, w);
+    const gptr_t pflux = VP_LATE_GPTR(LATE, I, flux);
+    const gptr_t pw = VP_LATE_GPTR(LATE, I, w);
     const double* __restrict__ pk = VP_LATE_FIELD(LATE, I, kflip);
     // the observed spectrum and its weights for this lane's pixels: in walker_kernel requested now, so that they travel
     // while the taps are applied -- behind the loop they are a memory round trip at the very end of the wave's, and the
@@ -1239,12 +1243,13 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
 #pragma unroll
             for (int r = 0; r < RB; ++r) { g[r] = pre.g[r]; wv[r] = pre.wv[r]; tau[r] = 0.0; }
         } else {
+            const gptr_t pg = VP_LATE_GPTR(W1, I, ginv), pwv = VP_LATE_GPTR(W1, I, wave);      // (once per pass)
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int i = min(base + r * 64 + lane, n_eval - 1);
                 const int q = min(max(q0 + i, 0), I.P - 1);   // edge replication = evaluate the clamped pixel
-                g[r] = VP_LATE_FIELD(W1, I, ginv)[q];
-                wv[r] = VP_LATE_FIELD(W1, I, wave)[q];
+                g[r] = pg[q];
+                wv[r] = pwv[q];
                 tau[r] = 0.0;
             }
         }
