@@ -154,12 +154,13 @@ __device__ __forceinline__ double exp_neg_tab(double t, const double* __restrict
     r = __builtin_fma(n, -LN2_8_LO, r);
     const int ni = (int)n;
     const double tj = et[ni & 7];
-    double p = 2.48015873015873015873e-05;                 // 1/8!
-    p = __builtin_fma(p, r, 1.98412698412698412698e-04);   // 1/7!
-    p = __builtin_fma(p, r, 1.38888888888888888889e-03);   // 1/6!
-    p = __builtin_fma(p, r, 8.33333333333333333333e-03);   // 1/120
-    p = __builtin_fma(p, r, 4.16666666666666666667e-02);
-    p = __builtin_fma(p, r, 1.66666666666666666667e-01);
+    // (Horner steps whose addend is a literal go through fma_s: the compiler's v_fmac form wants the addend in the destination
+    //  VGPRs and pays two v_mov_b32 per step for it -- ten VALU instructions of this function's twenty-nine)
+    double p = fma_s(r, 2.48015873015873015873e-05, 1.98412698412698412698e-04);   // 1/8!, 1/7!
+    p = fma_s(p, r, 1.38888888888888888889e-03);           // 1/6!
+    p = fma_s(p, r, 8.33333333333333333333e-03);           // 1/120
+    p = fma_s(p, r, 4.16666666666666666667e-02);
+    p = fma_s(p, r, 1.66666666666666666667e-01);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -171,8 +172,8 @@ __device__ __forceinline__ double exp_neg_tab(double t, const double* __restrict
 // ~19 instructions of exp_neg_tab -- C1 at 512 walkers: 41 of a walker's 72 chunks.
 constexpr double EXP_SMALL_MAX = 0x1p-10;
 __device__ __forceinline__ double exp_neg_small(double t) {
-    double p = __builtin_fma(t, -1.0 / 120.0, 1.0 / 24.0);
-    p = __builtin_fma(p, t, -1.0 / 6.0);
+    double p = fma_s(t, -1.0 / 120.0, 1.0 / 24.0);          // (literal addends as SGPR operands: fma_s)
+    p = fma_s(p, t, -1.0 / 6.0);
     p = __builtin_fma(p, t, 0.5);
     p = __builtin_fma(p, t, -1.0);
     return __builtin_fma(p, t, 1.0);
@@ -223,16 +224,15 @@ __device__ __forceinline__ double sinc_small(double t) {   // sin(t)/t
 }
 __device__ __forceinline__ double cos_small(double t) {
     const double t2 = t * t;
-    double p = 8.8967791632530450e-22;                 //  1/22!
-    p = __builtin_fma(p,t2, -4.1103176233121649e-19);  // -1/20!
-    p = __builtin_fma(p,t2, 1.5619206968586226e-16);   //  1/18!
-    p = __builtin_fma(p,t2, -4.7794773323873853e-14);  // -1/16!
-    p = __builtin_fma(p,t2, 1.1470745597729725e-11);   //  1/14!
-    p = __builtin_fma(p,t2, -2.0876756987868099e-09);  // -1/12!
-    p = __builtin_fma(p,t2, 2.7557319223985891e-07);   //  1/10!
-    p = __builtin_fma(p,t2, -2.4801587301587302e-05);  // -1/8!
-    p = __builtin_fma(p,t2, 1.3888888888888889e-03);   //  1/6!
-    p = __builtin_fma(p,t2, -4.1666666666666667e-02);  // -1/4!
+    double p = fma_s(t2, 8.8967791632530450e-22, -4.1103176233121649e-19);   //  1/22!, -1/20!
+    p = fma_s(p, t2, 1.5619206968586226e-16);          //  1/18!
+    p = fma_s(p, t2, -4.7794773323873853e-14);         // -1/16!
+    p = fma_s(p, t2, 1.1470745597729725e-11);          //  1/14!
+    p = fma_s(p, t2, -2.0876756987868099e-09);         // -1/12!
+    p = fma_s(p, t2, 2.7557319223985891e-07);          //  1/10!
+    p = fma_s(p, t2, -2.4801587301587302e-05);         // -1/8!
+    p = fma_s(p, t2, 1.3888888888888889e-03);          //  1/6!
+    p = fma_s(p, t2, -4.1666666666666667e-02);         // -1/4!
     p = __builtin_fma(p, t2, 0.5);
     return __builtin_fma(-p, t2, 1.0);
 }
@@ -240,9 +240,8 @@ __device__ __forceinline__ double cos_small(double t) {
 // cos(t) for |t| <= 0.1: five terms (t^10/10! < 3e-18)
 __device__ __forceinline__ double cos_tiny(double t) {
     const double t2 = t * t;
-    double p = 2.4801587301587302e-05;                   //  1/8!
-    p = __builtin_fma(p,t2, -1.3888888888888889e-03);   // -1/6!
-    p = __builtin_fma(p,t2, 4.1666666666666667e-02);    //  1/4!
+    double p = fma_s(t2, 2.4801587301587302e-05, -1.3888888888888889e-03);   //  1/8!, -1/6!
+    p = fma_s(p, t2, 4.1666666666666667e-02);           //  1/4!
     p = __builtin_fma(p, t2, -0.5);
     return __builtin_fma(p, t2, 1.0);
 }
