@@ -94,7 +94,14 @@ int vp_update_spectrum(vp_ctx* ctx, int inst, const double* flux, const double* 
  * Batches of up to 1 MiB of theta are read / written by the kernels straight from / to a pinned staging buffer, and the call
  * returns as soon as every output row has arrived there (the rows are pre-set to a NaN bit pattern that no arithmetic produces and
  * each is written exactly once; inputs carrying that payload make the call wait on a stream-written completion word instead):
- * `out` is complete and the context idle-equivalent when it returns, as with any synchronous call. */
+ * `out` is complete when it returns, as with any synchronous call.
+ * Pre-armed launches (option "prearm": -1 default, 0 never, 1 always; "prearm_us", default 300): for batches that are one
+ * walker_kernel launch, a call that came within prearm_us / 2 of the previous call's return leaves the launch for the NEXT batch
+ * of this shape on the GPU.  It has done everything that does not depend on theta and waits -- at most prearm_us microseconds,
+ * holding its compute units -- for the host to stage that batch; the next call then costs no launch: it copies theta, sets a
+ * word in pinned memory and waits for the rows.  Every other entry point of the context (and vp_ctx_destroy) sends a waiting
+ * launch away first; a launch that expired, or a batch of another shape, falls back to the ordinary launch.  Results do not
+ * depend on which way a batch was started.  vp_prearm_counts reports how often each happened. */
 int vp_lnprob_batch(vp_ctx* ctx, int W, int D, const double* theta, double* out);
 
 /* Same, operands already resident on the context's GPU; enqueued on `hip_stream` (a hipStream_t,
@@ -214,7 +221,7 @@ int vp_profile_read(vp_ctx* ctx, double* prep_ms, double* tile_ms, double* final
  * the per-call path.  Names: "geom" (-1 by batch size, 0 two-pass tiles, 1 one-pass tiles), "finalize"
  * (-1 auto, 0 own launch, 1 ticket), "walker" (-1 by batch size, 0 never, 1 whenever possible: the whole
  * batch as ONE launch, workgroup = walker), "prep_rpw", "zerocopy_max", "no_zerocopy", "no_fused_accept",
- * "slice_rows", "slice_seg", "tile_lpt", "walker_clusters"; "span", "waves", "no_multipole", "multipole_min", "lds_pad" and "farfield" (-1: per-block far-field
+ * "slice_rows", "slice_seg", "tile_lpt", "walker_clusters", "prearm", "prearm_us" (vp_lnprob_batch); "span", "waves", "no_multipole", "multipole_min", "lds_pad" and "farfield" (-1: per-block far-field
  * expansions for instruments with >= 8 lines in batches large enough to pay for the extra launch, 0 never, 1 whenever possible) apply to instruments added afterwards ("farfield" also at run time: 0 leaves the tables of an instrument unused, 1 uses them for every batch).
  * Unknown name -> VP_EINVAL.  (RBVFIT_AMD_VERBOSE in the environment makes vp_add_instrument print its far-field coverage
  * estimate to stderr; RBVFIT_AMD_LIB selects another build of the library in the Python loader.) */
@@ -281,6 +288,11 @@ int vp_last_launch_kind(const vp_ctx* ctx);
  * those of them whose line is a member of a multipole cluster (with variant 1 they entered with their whole cluster, with
  * variant 2 also one by one), *pairs = walkers x blocks x lines.  Any pointer may be NULL. */
 int vp_last_farfield_info(vp_ctx* ctx, int* variant, int64_t* covered, int64_t* covered_members, int64_t* pairs);
+
+/* Pre-armed launches of vp_lnprob_batch (option "prearm", see vp_lnprob_batch): how many calls were started through one
+ * (*used), how many such launches gave up waiting (*expired: the caller took longer than "prearm_us") and how many were sent away
+ * because another entry point -- or a batch of another shape -- came first (*cancelled).  Any pointer may be NULL. */
+int vp_prearm_counts(vp_ctx* ctx, int64_t* used, int64_t* expired, int64_t* cancelled);
 
 /* Text of the last error on this context (or of the last failed vp_ctx_create when ctx is NULL).
  * Valid until the next call on the same context/thread. */

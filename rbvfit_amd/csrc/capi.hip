@@ -80,6 +80,12 @@ struct Tuning {
     int stretch_overlap = -1;   // vp_stretch_run, half-steps as one launch each: -1 consecutive half-steps on two streams, ordered walker by
                                 // walker through version words (StretchArgs::ovl), where two half-ensembles fit the CUs at once; 0 never
                                 // (every half-step behind the one before, one stream); 1 whenever the half-steps are one launch each
+    int prearm = -1;            // vp_lnprob_batch, batches that are ONE walker_kernel launch: the launch for the NEXT call is put on the GPU
+                                // while this call's runs, waits there for its theta (WalkerArgs::arm_*) and starts the moment the host has
+                                // staged it -- no launch call, no command-processor latency and none of the kernel's theta-independent entry
+                                // between the caller's theta and the arithmetic.  -1: when the previous call came within prearm_us / 2 of the
+                                // one before returning (a sampler's loop), 0 never, 1 after every eligible call
+    int prearm_us = 300;        // how long a pre-armed launch waits for its batch before it leaves (the GPU is held meanwhile)
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
                                 // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
@@ -96,6 +102,7 @@ const Knob g_knobs[] = {
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
     VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
     VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0), VP_KNOB(walker_prio, "RBVFIT_AMD_WALKER_PRIO", 0), VP_KNOB(walker_perm_hex, "RBVFIT_AMD_WALKER_PERM_HEX", 1),
+    VP_KNOB(prearm, "RBVFIT_AMD_PREARM", 0), VP_KNOB(prearm_us, "RBVFIT_AMD_PREARM_US", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -187,6 +194,20 @@ struct vp_ctx {
     bool sentinel_armed = false;
     int sentinel_W = 0;
     const double* sentinel_out = nullptr;
+    // pre-armed launch of the next vp_lnprob_batch call (Tuning::prearm)
+    struct Prearm {
+        uint32_t* h = nullptr;        // pinned host block: h[0] go word, h[16] "expired" (by the launch), h[32] "stuck"
+        uint32_t* h_dev = nullptr;    // ... as the device sees it
+        uint32_t* d = nullptr;        // the launch's decision, device memory
+        bool live = false;            // a launch is waiting on the stream (or has expired there)
+        uint32_t seq = 0;             // ... with this sequence number
+        int W = 0;                    // ... for this many rows
+        bool inflight = false;        // the batch host_wait is waiting for was started through a pre-armed launch (seq_inflight)
+        uint32_t seq_inflight = 0;
+        bool have_last = false;       // last_return is set
+        std::chrono::steady_clock::time_point last_return;
+        int64_t used = 0, expired = 0, cancelled = 0;     // (vp_prearm_counts)
+    } arm;
     bool sentinel_unsafe = false;    // some static input (bounds, spectra, line tables, taps) carries the sentinel's NaN payload
     // direct-write gather of the lnprob vector between the ranks of a multi-process job (vp_gather_*)
     struct Gather {
@@ -549,9 +570,16 @@ int walker_prio_for(vp_ctx* c, int W) {
     return (c->num_cus > 0 && W <= c->num_cus) ? 0 : 1;
 }
 
-void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s, const vp::Replicas* gather = nullptr) {
-    const vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double)),
-                           walker_prio_for(c, W), walker_perm_for(c, W)};
+void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipStream_t s, const vp::Replicas* gather = nullptr,
+                   bool armed = false) {
+    vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double)),
+                     walker_prio_for(c, W), walker_perm_for(c, W)};
+    if (armed) {
+        a.arm_host = c->arm.h_dev;
+        a.arm_dev = c->arm.d;
+        a.arm_seq = c->arm.seq;
+        a.arm_ticks = 100 * std::max(1, c->tune.prearm_us);
+    }
     vp::StretchArgs st{};
     if (gather) st.rep = *gather;            // (the plain form's only use of the sampler arguments: where the results go)
     launch_walker_any<false>(c, W, a, st, s);
@@ -776,6 +804,42 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     return VP_OK;
 }
 
+// ---- pre-armed launches (Tuning::prearm, WalkerArgs::arm_*) -------------------------------------------------------------
+// (all called with c->mu held)
+// tell a waiting launch to leave: it has read nothing that depends on a batch and written nothing
+void prearm_cancel(vp_ctx* c) {
+    if (!c->arm.live) return;
+    __atomic_store_n(&c->arm.h[0], (c->arm.seq << 2) | (uint32_t)vp::ARM_LEAVE, __ATOMIC_RELEASE);
+    c->arm.live = false;
+    ++c->arm.cancelled;
+}
+// may the NEXT call of this shape be started through a pre-armed launch?
+bool prearm_eligible(vp_ctx* c, int W, size_t theta_bytes) {
+    return c->tune.prearm != 0 && c->tune.host_spin >= 2 && !c->sentinel_unsafe && !c->gather_rep && !c->profiling && c->policy_W == 0 &&
+           theta_bytes <= (size_t)std::max(0l, c->tune.zerocopy_max) && !c->tune.no_zerocopy && walker_applies(c, W);
+}
+int prearm_launch(vp_ctx* c, int W) {
+    if (!c->arm.h) {
+        if (hipHostMalloc((void**)&c->arm.h, 256, hipHostMallocMapped) != hipSuccess) { c->arm.h = nullptr; (void)hipGetLastError(); return VP_OK; }
+        std::memset(c->arm.h, 0, 256);
+        HIP_TRY(c, hipHostGetDevicePointer((void**)&c->arm.h_dev, c->arm.h, 0));
+        HIP_TRY(c, hipMalloc((void**)&c->arm.d, 64));
+        HIP_TRY(c, hipMemsetAsync(c->arm.d, 0, 64, c->stream));
+    }
+    c->arm.seq = (c->arm.seq + 1) & 0x3fffffffu;
+    if (c->arm.seq == 0) c->arm.seq = 1;
+    double* dp = c->h_pinned_dev;
+    launch_walker(c, W, dp, dp + (size_t)W * c->D, c->stream, nullptr, true);
+    HIP_TRY(c, hipGetLastError());
+    c->arm.live = true;
+    c->arm.W = W;
+    return VP_OK;
+}
+struct CtxGuard {                 // every entry but vp_lnprob_batch itself: lock the context and send a waiting launch away
+    std::lock_guard<std::mutex> g;
+    explicit CtxGuard(vp_ctx* c) : g(c->mu) { prearm_cancel(c); }
+};
+
 // (called with c->mu held)
 int check_batch_args(vp_ctx* c, int W, int D, const void* a, const void* b) {
     if (c->D <= 0) return fail(c, VP_ESTATE, "vp_set_bounds has not been called");
@@ -843,7 +907,7 @@ int vp_ctx_create(vp_ctx** out, int device_id) {
 
 int vp_set_option(vp_ctx* c, const char* name, long value) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     if (!name) return fail(c, VP_EINVAL, "vp_set_option: NULL name");
     for (const Knob& k : g_knobs)
         if (std::strcmp(k.name, name) == 0) {
@@ -869,8 +933,11 @@ static void gather_release(vp_ctx* c) {
 
 int vp_ctx_destroy(vp_ctx* c) {
     if (!c) return VP_OK;
+    { std::lock_guard<std::mutex> g(c->mu); prearm_cancel(c); }
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    if (c->arm.h) hipHostFree(c->arm.h);
+    if (c->arm.d) hipFree(c->arm.d);
     for (auto& in : c->inst) for (void* p : in.allocs) hipFree(p);
     for (void* p : {(void*)c->d_lb, (void*)c->d_ub, (void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial,
                     (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch,
@@ -890,7 +957,7 @@ int vp_ctx_destroy(vp_ctx* c) {
 
 int vp_set_bounds(vp_ctx* c, int D, const double* lb, const double* ub) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     if (D <= 0 || !lb || !ub) return fail(c, VP_EINVAL, "vp_set_bounds: D must be positive and lb/ub non-NULL");
     if (!c->inst.empty() && D != c->D) return fail(c, VP_ESTATE, "vp_set_bounds: D differs from the D the instruments were validated against");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -920,7 +987,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
                       const int32_t* v_idx, int K, const double* taps, int lsf_mode, int voigt_method,
                       int* inst_index) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     if (c->D <= 0) return fail(c, VP_ESTATE, "vp_add_instrument: call vp_set_bounds first (theta indices are validated against D)");
     if (P <= 0 || !wave || !flux || !inv_sigma2 || !log_inv_sigma2) return fail(c, VP_EINVAL, "vp_add_instrument: empty or NULL spectrum");
     if (L <= 0 || !lambda0 || !gamma || !f || !zfac || !N_idx || !b_idx || !v_idx) return fail(c, VP_EINVAL, "vp_add_instrument: empty or NULL line tables");
@@ -1202,7 +1269,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
 
 int vp_update_spectrum(vp_ctx* c, int inst, const double* flux, const double* inv_sigma2, const double* log_inv_sigma2) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_update_spectrum: instrument index out of range");
     if (!flux || !inv_sigma2 || !log_inv_sigma2) return fail(c, VP_EINVAL, "vp_update_spectrum: NULL array");
     Instrument& in = c->inst[inst];
@@ -1218,7 +1285,7 @@ int vp_update_spectrum(vp_ctx* c, int inst, const double* flux, const double* in
 
 int vp_lnprob_batch_device(vp_ctx* c, int W, int D, const double* d_theta, double* d_out, void* hip_stream) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     int rc = check_batch_args(c, W, D, d_theta, d_out);
     if (rc) return rc;
     if (W == 0) return VP_OK;
@@ -1257,7 +1324,7 @@ static vp::Replicas gather_replicas(const vp_ctx* c, int seq) {
 
 int vp_gather_create(vp_ctx* c, int W, int world, int rank, void* handles_out) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     if (W <= 0 || world <= 0 || world > vp::MAX_REPLICAS || rank < 0 || rank >= world || !handles_out)
         return fail(c, VP_EINVAL, "vp_gather_create: W > 0, 1 <= world <= " + std::to_string(vp::MAX_REPLICAS) + ", 0 <= rank < world and a handle buffer required");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1313,7 +1380,7 @@ int vp_gather_create(vp_ctx* c, int W, int world, int rank, void* handles_out) {
 
 int vp_gather_connect(vp_ctx* c, const void* handles_all, int shared_device) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     vp_ctx::Gather& G = c->gather;
     if (!G.buf) return fail(c, VP_ESTATE, "vp_gather_connect: call vp_gather_create first");
     G.shared_device = shared_device != 0;
@@ -1340,7 +1407,7 @@ int vp_gather_connect(vp_ctx* c, const void* handles_all, int shared_device) {
 
 int vp_lnprob_gather_device(vp_ctx* c, int W, int D, const double* d_theta, void* hip_stream) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     vp_ctx::Gather& G = c->gather;
     if (!G.connected) return fail(c, VP_ESTATE, "vp_lnprob_gather_device: no connected gather (vp_gather_create / vp_gather_connect)");
     int rc = check_batch_args(c, W, D, d_theta, G.buf);
@@ -1362,7 +1429,7 @@ int vp_lnprob_gather_device(vp_ctx* c, int W, int D, const double* d_theta, void
 
 int vp_gather_wait(vp_ctx* c, void* hip_stream) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     vp_ctx::Gather& G = c->gather;
     if (!G.connected) return fail(c, VP_ESTATE, "vp_gather_wait: no connected gather");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1374,7 +1441,7 @@ int vp_gather_wait(vp_ctx* c, void* hip_stream) {
 
 int vp_gather_state(vp_ctx* c, double** d_gathered, int* timed_out) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     vp_ctx::Gather& G = c->gather;
     if (!G.buf) return fail(c, VP_ESTATE, "vp_gather_state: no gather");
     if (d_gathered) *d_gathered = G.buf;
@@ -1389,7 +1456,7 @@ int vp_gather_state(vp_ctx* c, double** d_gathered, int* timed_out) {
 
 int vp_gather_destroy(vp_ctx* c) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     gather_release(c);
@@ -1398,11 +1465,23 @@ int vp_gather_destroy(vp_ctx* c) {
 
 // (called with c->mu held) host-buffer lnprob in two halves, so that several contexts (vp_multi) can have their
 // batches in flight at once: begin = stage theta + enqueue, end = wait + copy out
-static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta) {
+static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta, int arm_next = 0) {
     int rc;
+    const size_t tb = (size_t)W * D * sizeof(double), ob = (size_t)W * sizeof(double);
+    // a launch waiting for exactly this shape of batch?  (anything else: it leaves before the workspace may move)
+    bool use_armed = false;
+    if (c->arm.live) {
+        if (c->arm.W == W && arm_next >= 0 && prearm_eligible(c, W, tb) &&
+            __atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) != c->arm.seq)
+            use_armed = true;
+        else {
+            if (__atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) == c->arm.seq) { c->arm.live = false; ++c->arm.expired; }
+            prearm_cancel(c);
+        }
+    }
+    c->arm.inflight = false;
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
-    const size_t tb = (size_t)W * D * sizeof(double), ob = (size_t)W * sizeof(double);
     if ((rc = ensure_pinned(c, tb + ob))) return rc;
     std::memcpy(c->h_pinned, theta, tb);
     double* h_out = c->h_pinned + (size_t)W * D;
@@ -1418,13 +1497,25 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta) {
         // completion by the output rows themselves: every row is written exactly once per batch (out-of-bounds rows by the
         // launch that applies the prior, the others by the launch -- or the walker's last tile -- that finishes them)
         const bool poll_rows = c->tune.host_spin >= 2 && !c->sentinel_unsafe && !c->gather_rep && !carries_sentinel(theta, (size_t)W * D);
+        if (use_armed && !poll_rows) { prearm_cancel(c); use_armed = false; }
         if (poll_rows) {
             uint64_t* o = reinterpret_cast<uint64_t*>(h_out);
             for (int i = 0; i < W; ++i) o[i] = VP_SENTINEL_BITS;
             __atomic_thread_fence(__ATOMIC_RELEASE);
         }
-        if ((rc = enqueue_lnprob(c, W, dp, dp + (size_t)W * D, c->stream))) return rc;
+        if (use_armed) {
+            // theta and the pattern rows are in place: let the waiting launch go
+            __atomic_store_n(&c->arm.h[0], (c->arm.seq << 2) | (uint32_t)vp::ARM_GO, __ATOMIC_RELEASE);
+            c->arm.live = false;
+            c->arm.inflight = true;
+            c->arm.seq_inflight = c->arm.seq;
+            ++c->arm.used;
+            c->last_kind = 1;
+            c->last_ff = vp_ctx::LastFF{};
+        } else if ((rc = enqueue_lnprob(c, W, dp, dp + (size_t)W * D, c->stream))) return rc;
         if (poll_rows) {
+            // the launch for the caller's NEXT batch of this shape, behind this one on the stream
+            if (arm_next > 0 && prearm_eligible(c, W, tb) && (rc = prearm_launch(c, W))) return rc;
             c->sentinel_armed = true; c->sentinel_W = W; c->sentinel_out = h_out;
             VP_HSTAMP(1);
             return VP_OK;
@@ -1461,6 +1552,15 @@ static int host_wait(vp_ctx* c) {
         const int W = c->sentinel_W;
         const auto t0 = std::chrono::steady_clock::now();
         int i = 0;
+        // (a batch handed to a pre-armed launch: the launch may have given up waiting just before the go word came -- it says so,
+        //  has written nothing, and the batch is launched the ordinary way, after the launch armed behind it has been sent away)
+        auto relaunch = [&]() -> int {
+            c->arm.inflight = false;
+            prearm_cancel(c);
+            HIP_TRY(c, hipSetDevice(c->device));
+            double* dp = c->h_pinned_dev;
+            return enqueue_lnprob(c, W, dp, dp + (size_t)W * c->D, c->stream);
+        };
         for (unsigned int spins = 0; i < W; ++spins) {
             while (i < W && __atomic_load_n(o + i, __ATOMIC_ACQUIRE) != VP_SENTINEL_BITS) {
 #ifdef VP_STAMPS
@@ -1470,11 +1570,27 @@ static int host_wait(vp_ctx* c) {
             }
             if (i == W) { VP_HSTAMP(3); return VP_OK; }
             __builtin_ia32_pause();
+            if (c->arm.inflight && (spins & 63u) == 63u &&
+                __atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) == c->arm.seq_inflight) {
+                ++c->arm.expired; --c->arm.used;
+                int rc = relaunch();
+                if (rc) return rc;
+            }
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
         }
         if (i == W) return VP_OK;
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipStreamSynchronize(c->stream));     // (a long batch: the interrupt is cheap then; everything is written behind it)
+        if (c->arm.inflight) {
+            // ... unless workgroups of a pre-armed launch left on their own (arm_wait's last resort): rows still carry the pattern
+            bool missing = false;
+            for (int k = 0; k < W; ++k) missing |= __atomic_load_n(o + k, __ATOMIC_ACQUIRE) == VP_SENTINEL_BITS;
+            if (missing) {
+                int rc = relaunch();
+                if (rc) return rc;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+        }
         return VP_OK;
     }
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1507,8 +1623,25 @@ int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
 #ifdef VP_STAMPS
     g_host_t0 = std::chrono::steady_clock::now();
 #endif
-    if ((rc = lnprob_host_begin(c, W, D, theta))) return rc;
-    return lnprob_host_end(c, W, D, out);
+    // pre-arm the next call's launch?  (prearm = -1: when this call came quickly behind the last one's return -- a sampler's loop)
+    int arm_next = 0;
+    if (c->tune.prearm > 0) arm_next = 1;
+    else if (c->tune.prearm < 0 && c->arm.have_last)
+        arm_next = std::chrono::steady_clock::now() - c->arm.last_return < std::chrono::microseconds(std::max(1, c->tune.prearm_us / 2)) ? 1 : 0;
+    if ((rc = lnprob_host_begin(c, W, D, theta, arm_next))) return rc;
+    rc = lnprob_host_end(c, W, D, out);
+    c->arm.inflight = false;
+    c->arm.last_return = std::chrono::steady_clock::now();
+    c->arm.have_last = true;
+    return rc;
+}
+int vp_prearm_counts(vp_ctx* c, int64_t* used, int64_t* expired, int64_t* cancelled) {
+    if (!c) return VP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (used) *used = c->arm.used;
+    if (expired) *expired = c->arm.expired;
+    if (cancelled) *cancelled = c->arm.cancelled;
+    return VP_OK;
 }
 
 // (called with c->mu held) prep + tile launches that write the (W, P) model flux of one instrument
@@ -1551,7 +1684,7 @@ static int enqueue_model_flux(vp_ctx* c, int inst, int W, const double* d_theta,
 int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* d_theta, double* d_out, int convolved,
                                void* hip_stream) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     int rc = check_batch_args(c, W, D, d_theta, d_out);
     if (rc) return rc;
     if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_batch: instrument index out of range");
@@ -1562,7 +1695,7 @@ int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* 
 
 int vp_model_flux_batch(vp_ctx* c, int inst, int W, int D, const double* theta, double* out, int convolved) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);          // held from staging theta to the copy-back: d_theta / d_scratch are the context's
+    CtxGuard g(c);          // held from staging theta to the copy-back: d_theta / d_scratch are the context's
     int rc = check_batch_args(c, W, D, theta, out);
     if (rc) return rc;
     if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_batch: instrument index out of range");
@@ -1580,7 +1713,7 @@ int vp_model_flux_batch(vp_ctx* c, int inst, int W, int D, const double* theta, 
 
 int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* theta, double* out) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     int rc = check_batch_args(c, W, D, theta, out);
     if (rc) return rc;
     if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_components: instrument index out of range");
@@ -1618,7 +1751,7 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
 int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
                    uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     int rc = check_batch_args(c, W, D, pos, lnprob);
     if (rc) return rc;
     if (W < 2 || (W & 1)) return fail(c, VP_EINVAL, "vp_stretch_run: the number of walkers must be even and >= 2");
@@ -2019,7 +2152,7 @@ int vp_slice_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int have_
                  int* tune, double tolerance, int patience, int maxsteps, uint64_t seed, uint64_t step0,
                  double* chain, double* chain_lnprob, double* mu_history, int64_t* n_evals) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     int rc = check_batch_args(c, W, D, pos, lnprob);
     if (rc) return rc;
     int bad = 0;
@@ -2056,7 +2189,7 @@ void vp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]
 
 int vp_voigt_h(vp_ctx* c, int na, const double* a, int nx, const double* x, double* out) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     if (na <= 0 || nx <= 0 || !a || !x || !out) return fail(c, VP_EINVAL, "vp_voigt_h: empty or NULL input");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t rec = (size_t)na * vp::LC_STRIDE, need = (rec + na + nx + (size_t)na * nx) * sizeof(double);
@@ -2078,7 +2211,7 @@ int vp_voigt_h(vp_ctx* c, int na, const double* a, int nx, const double* x, doub
 
 int vp_profile_enable(vp_ctx* c, int enable) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     c->profiling = enable != 0;
     c->ev_used = 0;
     c->spans.clear();
@@ -2087,7 +2220,7 @@ int vp_profile_enable(vp_ctx* c, int enable) {
 
 int vp_profile_read(vp_ctx* c, double* prep_ms, double* tile_ms, double* finalize_ms, int* n_tile_launches) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     HIP_TRY(c, hipSetDevice(c->device));
     double acc[3] = {0, 0, 0};
     int ntile = 0;
@@ -2169,7 +2302,7 @@ static int multi_broken(vp_multi* m) {
 
 // (internal) drop the instrument added last to one context: the undo step of vp_multi_add_instrument
 static int ctx_pop_instrument(vp_ctx* c) {
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     if (c->inst.empty()) return VP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
@@ -2237,6 +2370,7 @@ int vp_multi_lnprob_batch(vp_multi* m, int W, int D, const double* theta, double
         const int lo = std::min(i * per, W), n = std::min(lo + per, W) - lo;
         vp_ctx* c = m->ctx[i];
         locks.emplace_back(c->mu);
+        prearm_cancel(c);
         if ((rc = check_batch_args(c, n, D, theta, out))) { multi_fail(m, i, rc); break; }
         if (n <= 0) continue;
         if ((rc = lnprob_host_begin(c, n, D, theta + (size_t)lo * D))) multi_fail(m, i, rc);
@@ -2288,7 +2422,7 @@ int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob,
     if (G > vp::MAX_REPLICAS) { m->err = "vp_multi_stretch_run: at most " + std::to_string(vp::MAX_REPLICAS) + " device contexts"; return VP_EINVAL; }
     if (m->no_peer) { m->err = "vp_multi_stretch_run: the devices cannot map each other's memory (no peer access)"; return VP_ESTATE; }
     std::vector<std::unique_lock<std::mutex>> locks;
-    for (int i = 0; i < G; ++i) locks.emplace_back(m->ctx[i]->mu);
+    for (int i = 0; i < G; ++i) { locks.emplace_back(m->ctx[i]->mu); prearm_cancel(m->ctx[i]); }
     int rc;
     for (int i = 0; i < G; ++i)
         if ((rc = check_batch_args(m->ctx[i], W, D, pos, lnprob))) return multi_fail(m, i, rc);
@@ -2498,7 +2632,7 @@ int vp_multi_slice_run(vp_multi* m, int W, int D, double* pos, double* lnprob, i
     if (G > vp::MAX_REPLICAS) { m->err = "vp_multi_slice_run: at most " + std::to_string(vp::MAX_REPLICAS) + " device contexts"; return VP_EINVAL; }
     if (m->no_peer) { m->err = "vp_multi_slice_run: the devices cannot map each other's memory (no peer access)"; return VP_ESTATE; }
     std::vector<std::unique_lock<std::mutex>> locks;
-    for (int i = 0; i < G; ++i) locks.emplace_back(m->ctx[i]->mu);
+    for (int i = 0; i < G; ++i) { locks.emplace_back(m->ctx[i]->mu); prearm_cancel(m->ctx[i]); }
     for (int i = 0; i < G; ++i)
         if (int rc = check_batch_args(m->ctx[i], W, D, pos, lnprob)) return multi_fail(m, i, rc);
     for (int i = (int)m->ev.size(); i < G; ++i) {
@@ -2535,7 +2669,7 @@ int vp_instrument_pixels(const vp_ctx* c, int inst) {
 int vp_device_id(const vp_ctx* c) { return c ? c->device : -1; }
 int vp_last_farfield_info(vp_ctx* c, int* variant, int64_t* covered, int64_t* covered_members, int64_t* pairs) {
     if (!c) return VP_EINVAL;
-    std::lock_guard<std::mutex> g(c->mu);
+    CtxGuard g(c);
     if (variant) *variant = 0;
     if (covered) *covered = 0;
     if (covered_members) *covered_members = 0;

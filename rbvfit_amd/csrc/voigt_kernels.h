@@ -1781,7 +1781,50 @@ struct WalkerArgs {
     unsigned long long wperm;   // nibble k = the tile wave k evaluates (identity: 0xFEDCBA9876543210): the host's deal of the tiles to the
                            // waves by estimated cost (capi.hip: vp_add_instrument, walker_perm_for).  Tile sums still meet in LDS by
                            // TILE index, so results do not depend on it
+    // Pre-armed launch (arm_dev != NULL; capi.hip: vp_lnprob_batch): the launch is ON the GPU before its batch exists.  Its waves
+    // do everything that does not need theta (kernel arguments, pixel loads, table staging) and then wait: wave 0 of workgroup 0
+    // polls the host's word arm_host[0] (pinned host memory; (arm_seq << 2) | code, code 1 = the batch is in place, 2 = leave)
+    // and passes the decision on through arm_dev (device memory, agent scope), which the record waves of every other workgroup
+    // poll.  The wait is bounded (arm_ticks of the 100 MHz clock): on expiry the poller says so in arm_host[16] and everyone
+    // leaves without having written anything.  ONE wave decides, so a launch either runs for the whole batch or not at all.
+    const unsigned int* arm_host;
+    unsigned int* arm_dev;
+    unsigned int arm_seq;
+    int arm_ticks;
 };
+
+constexpr int ARM_GO = 1, ARM_LEAVE = 2;
+constexpr int ARM_EXPIRED_WORD = 16, ARM_STUCK_WORD = 32;      // (in units of 4 bytes: separate cache lines of the host block)
+// (wave-uniform) the decision for this launch
+__device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int lane) {
+    unsigned int v = 0;
+    if (w == 0 && wid == 0) {
+        const long long t0 = wall_clock64();
+        int code = ARM_LEAVE;
+        for (int spins = 0;; ++spins) {
+            v = __hip_atomic_load(A.arm_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((v >> 2) == A.arm_seq) { code = (int)(v & 3u); break; }
+            if (wall_clock64() - t0 > (long long)A.arm_ticks || spins > (1 << 20)) {     // (the count: should the clock ever stand still)
+                if (lane == 0) __hip_atomic_store(const_cast<unsigned int*>(A.arm_host) + ARM_EXPIRED_WORD, A.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        code = __builtin_amdgcn_readfirstlane(code);
+        if (lane == 0) __hip_atomic_store(A.arm_dev, (A.arm_seq << 2) | (unsigned int)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return code;
+    }
+    for (int spins = 0;; ++spins) {
+        v = __hip_atomic_load(A.arm_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 2) == A.arm_seq) break;
+        if (spins > SYNC_SPIN_LIMIT) {           // (workgroup 0 decides within arm_ticks: never met; the host relaunches the batch)
+            if (lane == 0) __hip_atomic_store(const_cast<unsigned int*>(A.arm_host) + ARM_STUCK_WORD, A.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return ARM_LEAVE;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return __builtin_amdgcn_readfirstlane((int)(v & 3u));
+}
 
 // Where a walker's lnprob goes (one thread per workgroup): the batch's output vector, and -- direct-write gather of a
 // multi-rank job, R.n > 0 -- this rank's block of the gathered vector of EVERY rank (R.lp[r], peer-mapped, 8 bytes per walker
@@ -1847,6 +1890,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     // form -- formed here: z ~ g(z) on [1/a, a], partner j from the complementary half, Y = X_j - (X_j - X_k) z
     // (stretch_propose's arithmetic; every wave repeats the few instructions instead of waiting for one)
     double thv;
+    int arm_code = ARM_GO;
     double* __restrict__ stash = red + nw + 2;     // sampler form: [0] (D-1) ln z, [1] ln u, [2] lnprob of X_k, [4 + lane] X_k, [68 + lane] Y
     if (SAMPLER) {
         replicas_wait(S.rep);                    // (sharded ensemble: the complementary half as the peers left it)
@@ -1891,6 +1935,15 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             stash[68 + lane] = thv;
         }
     } else {
+        if (A.arm_dev) {
+            // pre-armed launch: the waves that need theta before the workgroup's barrier wait for the batch; the others go on
+            const bool theta_wave = wid < 1 + ((T.L + 3) >> 2) + (CLUSTERS ? ((T.NCm + 63) >> 6) : 0);
+            thv = 0.0;
+            if (theta_wave) {
+                arm_code = arm_wait(A, w, wid, lane);
+                if (arm_code == ARM_GO) thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
+            }
+        } else
         thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
         // direct-write gather (vp_gather_*): the batch before this one has arrived here from every rank before this one
         // computes -- the dependency of an ensemble step on the whole ensemble's lnprob, as a blocking all-gather states it
@@ -1913,6 +1966,9 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     const int hint_v = METHOD == 0 ? I.core_hint[lt] : 0;
     const int ngrp = (T.L + 3) >> 2, ncl = CLUSTERS ? ((T.NCm + 63) >> 6) : 0;
     const int ntask = 1 + ngrp + ncl;              // task 0: box prior; then line groups; then cluster records
+    if (!SAMPLER && arm_code != ARM_GO) {
+        if (tid == 0) red[nw] = 2.0;                  // (pre-armed launch told to leave: nobody evaluates or writes anything)
+    } else
     for (int task = wid; task < ntask; task += nw) {
         if (task == 0) {
             const bool oob = lane < A.D && ((thv < A.lb[min(lane, A.D - 1)]) || (thv > A.ub[min(lane, A.D - 1)]));
@@ -1947,6 +2003,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     if (daw_ready && A.prio) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
 #endif
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
+    if (!SAMPLER && red[nw] == 2.0) return;
     if (oobw && !SAMPLER) {
         if (tid == 0) walker_result(A, S.rep, w, -__builtin_inf());
         return;

@@ -355,6 +355,15 @@ class Engine:
         return dict(variant={0: "none", 1: "lines+clusters", 2: "members"}[v.value], covered=a.value,
                     covered_members=b.value, pairs=n.value)
 
+    @property
+    def prearm_counts(self) -> dict:
+        """Pre-armed launches of the host-buffer lnprob entry (``vp_prearm_counts``; option "prearm"): calls started through
+        one (``used``), launches that gave up waiting (``expired``) and launches sent away unused (``cancelled``)."""
+        self._guard()
+        u, e, x = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.vp_prearm_counts(self._ctx, C.byref(u), C.byref(e), C.byref(x)))
+        return dict(used=u.value, expired=e.value, cancelled=x.value)
+
     # -- per-kernel timing (HIP events on the launch stream) ------------------------------------
     def profile_enable(self, on: bool = True):
         self._guard()

@@ -350,3 +350,71 @@ def test_host_entry_completion_modes_agree(structure):
                            g("N_idx"), g("b_idx"), g("v_idx"), taps=g("taps"), lsf_mode=int(g("lsf_mode")), voigt_method=int(g("voigt_method")))
         c = eng.lnprob(th)
     assert np.array_equal(np.isneginf(c), np.isneginf(res[2])) and np.all(np.isnan(c[~np.isneginf(c)]))
+
+
+def test_prearmed_launches_change_nothing():
+    """vp_lnprob_batch may leave the launch for the NEXT batch waiting on the GPU (option "prearm").  Whatever happens to that
+    launch -- used by the next call, expired because the caller took too long, sent away by another entry point or by a batch
+    of another shape, told to go for a batch with rows outside the box or a NaN -- the call returns the bits the ordinary launch
+    returns, and the counters say which of these happened."""
+    import time
+    z = load_golden("c0_mgii")
+    rng = np.random.default_rng(5)
+    base = np.tile(z["thetas"], (4, 1))[:100].copy()
+    batches = []
+    for k in range(6):
+        th = base + 1e-3 * rng.standard_normal(base.shape) * (z["ub"] - z["lb"])
+        th = np.clip(th, z["lb"], z["ub"])
+        batches.append(th)
+    batches[2][3, 0] = z["lb"][0] - 1.0               # -inf row
+    batches[3][40, 2] = np.nan                        # NaN row
+    with engine_from_fixture(z) as ref:
+        ref.set_option("prearm", 0)
+        ref.set_option("walker", 1)
+        want = [ref.lnprob(th) for th in batches]
+        want_small = ref.lnprob(batches[0][:32])
+        flux = ref.model_flux(0, batches[0][:2])
+        assert ref.prearm_counts == dict(used=0, expired=0, cancelled=0)
+    assert np.isneginf(want[2][3]) and np.isnan(want[3][40])
+    with engine_from_fixture(z) as eng:
+        eng.set_option("prearm", 1)
+        eng.set_option("walker", 1)
+        # back to back: every call after the first starts through the launch the call before left behind
+        for rep in range(20):
+            for th, w in zip(batches, want):
+                assert np.array_equal(eng.lnprob(th), w, equal_nan=True)
+        c = eng.prearm_counts
+        assert c["used"] >= 100 and c["cancelled"] == 0, c
+        # another entry point in between: the waiting launch is sent away, both results are right
+        np.testing.assert_array_equal(eng.model_flux(0, batches[0][:2]), flux)
+        assert np.array_equal(eng.lnprob(batches[1]), want[1], equal_nan=True)
+        assert eng.prearm_counts["cancelled"] == c["cancelled"] + 1
+        # a batch of another shape
+        assert np.array_equal(eng.lnprob(batches[0][:32]), want_small)
+        assert np.array_equal(eng.lnprob(batches[4]), want[4])
+        assert eng.prearm_counts["cancelled"] >= c["cancelled"] + 3
+        # a caller that takes longer than the launch waits
+        eng.set_option("prearm_us", 50)
+        assert np.array_equal(eng.lnprob(batches[5]), want[5])
+        e0 = eng.prearm_counts["expired"]
+        for k in range(5):
+            time.sleep(0.005)
+            assert np.array_equal(eng.lnprob(batches[k]), want[k], equal_nan=True)
+        assert eng.prearm_counts["expired"] >= e0 + 4, eng.prearm_counts
+        # ... and one whose go word races the expiry (gaps around the waiting time): right either way
+        for k in range(300):
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < (20 + (k % 61)) * 1e-6:
+                pass
+            assert np.array_equal(eng.lnprob(batches[k % 6]), want[k % 6], equal_nan=True)
+    # by default (prearm = -1) a loop of calls arms, a lone call does not
+    with engine_from_fixture(z) as eng:
+        eng.set_option("walker", 1)
+        eng.lnprob(batches[0])
+        assert eng.prearm_counts == dict(used=0, expired=0, cancelled=0)
+        time.sleep(0.01)
+        eng.lnprob(batches[0])
+        assert eng.prearm_counts["used"] == 0
+        for _ in range(20):
+            assert np.array_equal(eng.lnprob(batches[0]), want[0])
+        assert eng.prearm_counts["used"] >= 15
