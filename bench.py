@@ -636,7 +636,34 @@ def rank_main(args):
                 fn(ctx, W, D, pa, pb)
             raw_us = 1e6 * (time.perf_counter() - th0) / nraw
             assert np.array_equal(np.nan_to_num(out_raw), np.nan_to_num(ref_host)), "raw C-ABI call differs from the wrapper"
+            # ... and what the pre-armed launch of the next call contributes (vp_lnprob_batch, option "prearm"): the same loop with
+            # it switched off, and both forms as a caller with 100 us of its own work between calls sees them
+            def paced(n, gap_s):
+                tot = 0.0
+                for _ in range(n):
+                    t1 = time.perf_counter()
+                    while time.perf_counter() - t1 < gap_s:
+                        pass
+                    t1 = time.perf_counter(); wl.engine.lnprob(th_host); tot += time.perf_counter() - t1
+                return 1e6 * tot / n
+            prearm_counts = dict(wl.engine.prearm_counts)
+            paced_on = paced(2000, 100e-6)
+            wl.engine.set_option("prearm", 0)
+            for _ in range(20):
+                wl.engine.lnprob(th_host)
+            noff = min(ncall, 20000)
+            th0 = time.perf_counter()
+            for _ in range(noff):
+                wl.engine.lnprob(th_host)
+            off_us = 1e6 * (time.perf_counter() - th0) / noff
+            paced_off = paced(2000, 100e-6)
+            wl.engine.set_option("prearm", -1)
             host_lat = dict(us_per_call=1e6 * wall / ncall, calls=ncall, seconds=wall, walkers_per_call=W,
+                            prearm=dict(counts_after_timed_loop=prearm_counts, us_per_call_without=off_us,
+                                        us_per_call_caller_with_100us_between_calls=paced_on,
+                                        us_per_call_caller_with_100us_between_calls_without=paced_off,
+                                        note="vp_lnprob_batch leaves the NEXT call's launch waiting on the GPU for its theta when calls "
+                                             "follow each other within prearm_us / 2 (include/rbvfit_amd.h); 'without' = option prearm 0"),
                             median_us=1e6 * float(np.median(lat)), p10_us=1e6 * float(lat[nlat // 10]),
                             p90_us=1e6 * float(lat[(9 * nlat) // 10]), latency_sample=nlat,
                             us_per_call_bare_cabi=raw_us, python_wrapper_us=1e6 * wall / ncall - raw_us,

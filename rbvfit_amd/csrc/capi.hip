@@ -85,7 +85,7 @@ struct Tuning {
                                 // staged it -- no launch call, no command-processor latency and none of the kernel's theta-independent entry
                                 // between the caller's theta and the arithmetic.  -1: when the previous call came within prearm_us / 2 of the
                                 // one before returning (a sampler's loop), 0 never, 1 after every eligible call
-    int prearm_us = 300;        // how long a pre-armed launch waits for its batch before it leaves (the GPU is held meanwhile)
+    int prearm_us = 1000;       // how long a pre-armed launch waits for its batch before it leaves (the GPU is held meanwhile)
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
                                 // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
@@ -202,6 +202,8 @@ struct vp_ctx {
         bool live = false;            // a launch is waiting on the stream (or has expired there)
         uint32_t seq = 0;             // ... with this sequence number
         int W = 0;                    // ... for this many rows
+        hipStream_t cur = nullptr;    // the stream of the launch that serves the current call
+        hipStream_t live_stream = nullptr;    // the stream the waiting launch is on
         bool inflight = false;        // the batch host_wait is waiting for was started through a pre-armed launch (seq_inflight)
         uint32_t seq_inflight = 0;
         bool have_last = false;       // last_return is set
@@ -823,15 +825,18 @@ int prearm_launch(vp_ctx* c, int W) {
         if (hipHostMalloc((void**)&c->arm.h, 256, hipHostMallocMapped) != hipSuccess) { c->arm.h = nullptr; (void)hipGetLastError(); return VP_OK; }
         std::memset(c->arm.h, 0, 256);
         HIP_TRY(c, hipHostGetDevicePointer((void**)&c->arm.h_dev, c->arm.h, 0));
-        HIP_TRY(c, hipMalloc((void**)&c->arm.d, 64));
-        HIP_TRY(c, hipMemsetAsync(c->arm.d, 0, 64, c->stream));
+        HIP_TRY(c, hipMalloc((void**)&c->arm.d, 4 * vp::ARM_DEV_WORDS * vp::ARM_DEV_STRIDE));
+        HIP_TRY(c, hipMemset(c->arm.d, 0, 4 * vp::ARM_DEV_WORDS * vp::ARM_DEV_STRIDE));
+        HIP_TRY(c, hipDeviceSynchronize());
     }
     c->arm.seq = (c->arm.seq + 1) & 0x3fffffffu;
     if (c->arm.seq == 0) c->arm.seq = 1;
+    hipStream_t s = c->stream;
     double* dp = c->h_pinned_dev;
-    launch_walker(c, W, dp, dp + (size_t)W * c->D, c->stream, nullptr, true);
+    launch_walker(c, W, dp, dp + (size_t)W * c->D, s, nullptr, true);
     HIP_TRY(c, hipGetLastError());
     c->arm.live = true;
+    c->arm.live_stream = s;
     c->arm.W = W;
     return VP_OK;
 }
@@ -1508,11 +1513,15 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta, int a
             __atomic_store_n(&c->arm.h[0], (c->arm.seq << 2) | (uint32_t)vp::ARM_GO, __ATOMIC_RELEASE);
             c->arm.live = false;
             c->arm.inflight = true;
+            c->arm.cur = c->arm.live_stream;
             c->arm.seq_inflight = c->arm.seq;
             ++c->arm.used;
             c->last_kind = 1;
             c->last_ff = vp_ctx::LastFF{};
-        } else if ((rc = enqueue_lnprob(c, W, dp, dp + (size_t)W * D, c->stream))) return rc;
+        } else {
+            c->arm.cur = c->stream;
+            if ((rc = enqueue_lnprob(c, W, dp, dp + (size_t)W * D, c->stream))) return rc;
+        }
         if (poll_rows) {
             // the launch for the caller's NEXT batch of this shape, behind this one on the stream
             if (arm_next > 0 && prearm_eligible(c, W, tb) && (rc = prearm_launch(c, W))) return rc;
@@ -1558,6 +1567,7 @@ static int host_wait(vp_ctx* c) {
             c->arm.inflight = false;
             prearm_cancel(c);
             HIP_TRY(c, hipSetDevice(c->device));
+            c->arm.cur = c->stream;
             double* dp = c->h_pinned_dev;
             return enqueue_lnprob(c, W, dp, dp + (size_t)W * c->D, c->stream);
         };
@@ -1580,7 +1590,7 @@ static int host_wait(vp_ctx* c) {
         }
         if (i == W) return VP_OK;
         HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));     // (a long batch: the interrupt is cheap then; everything is written behind it)
+        HIP_TRY(c, hipStreamSynchronize(c->arm.inflight && c->arm.cur ? c->arm.cur : c->stream));     // (a long batch: the interrupt is cheap then; everything is written behind it)
         if (c->arm.inflight) {
             // ... unless workgroups of a pre-armed launch left on their own (arm_wait's last resort): rows still carry the pattern
             bool missing = false;

@@ -829,12 +829,15 @@ constexpr int STAMP_W = 1024, STAMP_WAVES = 16, STAMP_STAGES = 16;
 __device__ long long g_stamps[STAMP_W * STAMP_WAVES * STAMP_STAGES];
 #define VP_STAMP(stage) do { if (g_stamp_w >= 0 && g_stamp_w < STAMP_W && (threadIdx.x & 63) == 0) \
     g_stamps[(g_stamp_w * STAMP_WAVES + (int)(threadIdx.x >> 6)) * STAMP_STAGES + (stage)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define VP_STAMP_RT(stage) do { if (g_stamp_w >= 0 && g_stamp_w < STAMP_W && (threadIdx.x & 63) == 0) \
+    g_stamps[(g_stamp_w * STAMP_WAVES + (int)(threadIdx.x >> 6)) * STAMP_STAGES + (stage)] = (long long)wall_clock64(); } while (0)   /* 100 MHz, one base for all XCDs */
 #define VP_STAMP_DECL const int g_stamp_w = (int)blockIdx.x;
 #define VP_STAMP_ARG , const int g_stamp_w
 #define VP_STAMP_PASS , g_stamp_w
 #define VP_STAMP_NONE , -1
 #else
 #define VP_STAMP(stage) do { } while (0)
+#define VP_STAMP_RT(stage) do { } while (0)
 #define VP_STAMP_DECL
 #define VP_STAMP_ARG
 #define VP_STAMP_PASS
@@ -1794,6 +1797,7 @@ struct WalkerArgs {
 };
 
 constexpr int ARM_GO = 1, ARM_LEAVE = 2;
+constexpr int ARM_DEV_WORDS = 64, ARM_DEV_STRIDE = 16;         // the decision in device memory: 64 copies, 64 bytes apart
 constexpr int ARM_EXPIRED_WORD = 16, ARM_STUCK_WORD = 32;      // (in units of 4 bytes: separate cache lines of the host block)
 // (wave-uniform) the decision for this launch
 __device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int lane) {
@@ -1801,6 +1805,9 @@ __device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int
     if (w == 0 && wid == 0) {
         const long long t0 = wall_clock64();
         int code = ARM_LEAVE;
+        // (one read at a time: a PCIe round trip of 1.3-1.9 us each.  Four in flight, a new one every 0.35 us, were built and
+        //  measured: the reads still in flight when the word comes have to be waited for before the wave goes on, which costs
+        //  what the finer sampling gains -- profiles/r04_notes.md)
         for (int spins = 0;; ++spins) {
             v = __hip_atomic_load(A.arm_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((v >> 2) == A.arm_seq) { code = (int)(v & 3u); break; }
@@ -1811,11 +1818,14 @@ __device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int
             __builtin_amdgcn_s_sleep(1);
         }
         code = __builtin_amdgcn_readfirstlane(code);
-        if (lane == 0) __hip_atomic_store(A.arm_dev, (A.arm_seq << 2) | (unsigned int)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (ARM_DEV_WORDS copies, a cache line each: a thousand waves polling ONE word queue up behind each other -- and this store
+        //  behind them)
+        __hip_atomic_store(A.arm_dev + ARM_DEV_STRIDE * (lane & (ARM_DEV_WORDS - 1)), (A.arm_seq << 2) | (unsigned int)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return code;
     }
+    const unsigned int* mine = A.arm_dev + ARM_DEV_STRIDE * ((2 * w + wid) & (ARM_DEV_WORDS - 1));
     for (int spins = 0;; ++spins) {
-        v = __hip_atomic_load(A.arm_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((v >> 2) == A.arm_seq) break;
         if (spins > SYNC_SPIN_LIMIT) {           // (workgroup 0 decides within arm_ticks: never met; the host relaunches the batch)
             if (lane == 0) __hip_atomic_store(const_cast<unsigned int*>(A.arm_host) + ARM_STUCK_WORD, A.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1870,6 +1880,10 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     extern __shared__ double smem[];
     VP_STAMP_DECL
     VP_STAMP(0);
+#ifdef VP_STAMPS
+    const long long rt_entry = wall_clock64();      // (written behind the barrier, and only by launches that run: a pre-armed launch
+    long long rt_go = rt_entry;                     //  that leaves must not overwrite the stamps of the launch before it)
+#endif
 #ifdef VP_STAMPS
     {   // where the wave runs: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]) | XCC_ID << 32
         unsigned int hwid, xcc;
@@ -1941,6 +1955,9 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             thv = 0.0;
             if (theta_wave) {
                 arm_code = arm_wait(A, w, wid, lane);
+#ifdef VP_STAMPS
+                rt_go = wall_clock64();
+#endif
                 if (arm_code == ARM_GO) thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
             }
         } else
@@ -1995,6 +2012,12 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     VP_STAMP(11);
     __syncthreads();
     VP_STAMP(1);
+#ifdef VP_STAMPS
+    if (red[nw] != 2.0 && lane == 0 && w < STAMP_W) {
+        long long* gs = g_stamps + (w * STAMP_WAVES + wid) * STAMP_STAGES;
+        gs[14] = rt_entry; gs[12] = rt_go; gs[13] = wall_clock64();
+    }
+#endif
 #ifndef VP_NO_PRIO
     // the tiles with line cores are the workgroup's critical path (twice the work of the others): their waves go first
     // on their SIMDs from the start where the hint says so, from phase B on otherwise
@@ -2018,6 +2041,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         if (lane == 0) red[tw] = wsum;
         __syncthreads();
         VP_STAMP(5);
+        VP_STAMP_RT(15);
         if (wid != 0) return;
         double sk = 0.0;
         const int n0 = NI > 1 ? tb.t[0] : nw;

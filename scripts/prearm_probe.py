@@ -3,7 +3,7 @@
     python scripts/prearm_probe.py [walkers ...]
 
 us per call by walker count (median and mean over back-to-back calls), the counters, and what a caller that pauses between its
-calls gets (busy wait of the given length between return and the next call: the launch waits `prearm_us` = 300 us)."""
+calls gets (busy wait of the given length between return and the next call: the launch waits `prearm_us` = 1000 us, and is left behind when calls come within half of that)."""
 import os
 import sys
 import time
@@ -45,7 +45,7 @@ def main():
             line = f"{cfg} W={W} prearm={mode:2d}: {med:.2f} us/call median, {mean:.2f} mean ({W / mean:.2f} M evals/s) same_bits={same} {eng.prearm_counts}"
             if mode != 0:
                 gaps = []
-                for gap in (20, 100, 250, 400):
+                for gap in (20, 100, 400, 800):
                     m2, _ = run(eng, th, 300, gap)
                     gaps.append(f"gap {gap} us: {m2:.2f}")
                 line += " | " + ", ".join(gaps) + f" {eng.prearm_counts}"
