@@ -196,9 +196,12 @@ struct vp_ctx {
     const double* sentinel_out = nullptr;
     // pre-armed launch of the next vp_lnprob_batch call (Tuning::prearm)
     struct Prearm {
-        uint32_t* h = nullptr;        // pinned host block: h[0] go word, h[16] "expired" (by the launch), h[32] "stuck"
+        uint32_t* h = nullptr;        // pinned host block the LAUNCH writes: h[16] "expired", h[32] "stuck"
         uint32_t* h_dev = nullptr;    // ... as the device sees it
-        uint32_t* d = nullptr;        // the launch's decision, device memory
+        int bar = -1;                 // can the CPU write device memory (large BAR)?  -1 not asked yet
+        double* slots = nullptr;      // fine-grained device memory the CPU writes through the BAR: slot_doubles per row (WalkerArgs::arm_slots)
+        int slot_doubles = 0, slot_rows = 0;
+        const double* theta_src = nullptr;    // the caller's theta of the batch in flight (only the slots have it so far)
         bool live = false;            // a launch is waiting on the stream (or has expired there)
         uint32_t seq = 0;             // ... with this sequence number
         int W = 0;                    // ... for this many rows
@@ -577,8 +580,9 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, c->inst[0].sum_logw, c->D, (int)(walker_wave_lds(c) / sizeof(double)),
                      walker_prio_for(c, W), walker_perm_for(c, W)};
     if (armed) {
+        a.arm_slots = c->arm.slots;
+        a.arm_slot_doubles = c->arm.slot_doubles;
         a.arm_host = c->arm.h_dev;
-        a.arm_dev = c->arm.d;
         a.arm_seq = c->arm.seq;
         a.arm_ticks = 100 * std::max(1, c->tune.prearm_us);
     }
@@ -808,26 +812,70 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
 
 // ---- pre-armed launches (Tuning::prearm, WalkerArgs::arm_*) -------------------------------------------------------------
 // (all called with c->mu held)
+// what the host writes into the slots (through the BAR: stores only, never a load; the word goes last)
+void prearm_push(vp_ctx* c, int W, const double* theta, int code) {
+    const int n = c->arm.slot_doubles, D = c->D;
+    const uint64_t word = ((uint64_t)c->arm.seq << 2) | (uint64_t)code;
+    double* s = c->arm.slots;
+    if (!theta) {
+        for (int w = 0; w < W; ++w) reinterpret_cast<volatile uint64_t*>(s + (size_t)w * n)[n - 1] = word;
+    } else if (n == 8) {
+        // one 64-byte line per row: the row, padding, the word -- written in address order, so the write-combining buffer goes out
+        // as one burst (should it be cut in two, the earlier bytes still arrive first)
+        for (int w = 0; w < W; ++w) {
+            volatile double* q = s + (size_t)w * 8;
+            const double* t = theta + (size_t)w * D;
+            int k = 0;
+            for (; k < D; ++k) q[k] = t[k];
+            for (; k < 7; ++k) q[k] = 0.0;
+            reinterpret_cast<volatile uint64_t*>(q)[7] = word;
+        }
+    } else {
+        for (int w = 0; w < W; ++w) std::memcpy(s + (size_t)w * n, theta + (size_t)w * D, (size_t)D * sizeof(double));
+        __builtin_ia32_sfence();            // rows before words (write-combining buffers of different lines go out in any order)
+        for (int w = 0; w < W; ++w) reinterpret_cast<volatile uint64_t*>(s + (size_t)w * n)[n - 1] = word;
+    }
+    __builtin_ia32_sfence();
+}
 // tell a waiting launch to leave: it has read nothing that depends on a batch and written nothing
 void prearm_cancel(vp_ctx* c) {
     if (!c->arm.live) return;
-    __atomic_store_n(&c->arm.h[0], (c->arm.seq << 2) | (uint32_t)vp::ARM_LEAVE, __ATOMIC_RELEASE);
+    prearm_push(c, c->arm.W, nullptr, vp::ARM_LEAVE);
     c->arm.live = false;
     ++c->arm.cancelled;
 }
 // may the NEXT call of this shape be started through a pre-armed launch?
 bool prearm_eligible(vp_ctx* c, int W, size_t theta_bytes) {
-    return c->tune.prearm != 0 && c->tune.host_spin >= 2 && !c->sentinel_unsafe && !c->gather_rep && !c->profiling && c->policy_W == 0 &&
+    return c->tune.prearm != 0 && c->arm.bar != 0 && c->tune.host_spin >= 2 && !c->sentinel_unsafe && !c->gather_rep && !c->profiling && c->policy_W == 0 &&
            theta_bytes <= (size_t)std::max(0l, c->tune.zerocopy_max) && !c->tune.no_zerocopy && walker_applies(c, W);
 }
 int prearm_launch(vp_ctx* c, int W) {
+    if (c->arm.bar < 0) {
+        // device memory the CPU can write: every GPU of this class has its whole memory behind the PCIe BAR; without it there
+        // are no pre-armed launches
+        int v = 0;
+        c->arm.bar = (hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && v) ? 1 : 0;
+        (void)hipGetLastError();
+        if (!c->arm.bar) return VP_OK;
+    }
     if (!c->arm.h) {
-        if (hipHostMalloc((void**)&c->arm.h, 256, hipHostMallocMapped) != hipSuccess) { c->arm.h = nullptr; (void)hipGetLastError(); return VP_OK; }
+        if (hipHostMalloc((void**)&c->arm.h, 256, hipHostMallocMapped) != hipSuccess) { c->arm.h = nullptr; c->arm.bar = 0; (void)hipGetLastError(); return VP_OK; }
         std::memset(c->arm.h, 0, 256);
         HIP_TRY(c, hipHostGetDevicePointer((void**)&c->arm.h_dev, c->arm.h, 0));
-        HIP_TRY(c, hipMalloc((void**)&c->arm.d, 4 * vp::ARM_DEV_WORDS * vp::ARM_DEV_STRIDE));
-        HIP_TRY(c, hipMemset(c->arm.d, 0, 4 * vp::ARM_DEV_WORDS * vp::ARM_DEV_STRIDE));
+    }
+    const int n = 8 * ((c->D + 1 + 7) / 8);
+    if (!c->arm.slots || c->arm.slot_rows < W || c->arm.slot_doubles != n) {
+        // (no launch is waiting here: a batch of another shape has sent it away -- hipFree waits for it)
+        if (c->arm.slots) HIP_TRY(c, hipFree(c->arm.slots));
+        c->arm.slots = nullptr;
+        const size_t bytes = (size_t)W * n * sizeof(double);
+        if (hipExtMallocWithFlags((void**)&c->arm.slots, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            c->arm.slots = nullptr; c->arm.bar = 0; (void)hipGetLastError(); return VP_OK;
+        }
+        HIP_TRY(c, hipMemset(c->arm.slots, 0, bytes));
         HIP_TRY(c, hipDeviceSynchronize());
+        c->arm.slot_rows = W;
+        c->arm.slot_doubles = n;
     }
     c->arm.seq = (c->arm.seq + 1) & 0x3fffffffu;
     if (c->arm.seq == 0) c->arm.seq = 1;
@@ -942,7 +990,7 @@ int vp_ctx_destroy(vp_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     if (c->arm.h) hipHostFree(c->arm.h);
-    if (c->arm.d) hipFree(c->arm.d);
+    if (c->arm.slots) hipFree(c->arm.slots);
     for (auto& in : c->inst) for (void* p : in.allocs) hipFree(p);
     for (void* p : {(void*)c->d_lb, (void*)c->d_ub, (void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial,
                     (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch,
@@ -1488,7 +1536,7 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta, int a
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     if ((rc = ensure_pinned(c, tb + ob))) return rc;
-    std::memcpy(c->h_pinned, theta, tb);
+    if (!use_armed) std::memcpy(c->h_pinned, theta, tb);       // (a waiting launch gets theta pushed into its slots instead)
     double* h_out = c->h_pinned + (size_t)W * D;
     VP_HSTAMP(0);
     c->done_armed = false;
@@ -1502,15 +1550,16 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta, int a
         // completion by the output rows themselves: every row is written exactly once per batch (out-of-bounds rows by the
         // launch that applies the prior, the others by the launch -- or the walker's last tile -- that finishes them)
         const bool poll_rows = c->tune.host_spin >= 2 && !c->sentinel_unsafe && !c->gather_rep && !carries_sentinel(theta, (size_t)W * D);
-        if (use_armed && !poll_rows) { prearm_cancel(c); use_armed = false; }
+        if (use_armed && !poll_rows) { prearm_cancel(c); use_armed = false; std::memcpy(c->h_pinned, theta, tb); }
         if (poll_rows) {
             uint64_t* o = reinterpret_cast<uint64_t*>(h_out);
             for (int i = 0; i < W; ++i) o[i] = VP_SENTINEL_BITS;
             __atomic_thread_fence(__ATOMIC_RELEASE);
         }
         if (use_armed) {
-            // theta and the pattern rows are in place: let the waiting launch go
-            __atomic_store_n(&c->arm.h[0], (c->arm.seq << 2) | (uint32_t)vp::ARM_GO, __ATOMIC_RELEASE);
+            // the pattern rows are in place: push theta and the go words into the waiting launch's slots
+            prearm_push(c, W, theta, vp::ARM_GO);
+            c->arm.theta_src = theta;
             c->arm.live = false;
             c->arm.inflight = true;
             c->arm.cur = c->arm.live_stream;
@@ -1567,6 +1616,14 @@ static int host_wait(vp_ctx* c) {
             c->arm.inflight = false;
             prearm_cancel(c);
             HIP_TRY(c, hipSetDevice(c->device));
+            // some workgroups of the expired launch may have met their rows and run: nothing of it may still write when the
+            // rows are set to the pattern again
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            std::memcpy(c->h_pinned, c->arm.theta_src, (size_t)W * c->D * sizeof(double));
+            uint64_t* orow = const_cast<uint64_t*>(o);
+            for (int k = 0; k < W; ++k) orow[k] = VP_SENTINEL_BITS;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            i = 0;
             c->arm.cur = c->stream;
             double* dp = c->h_pinned_dev;
             return enqueue_lnprob(c, W, dp, dp + (size_t)W * c->D, c->stream);

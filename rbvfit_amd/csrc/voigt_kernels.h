@@ -1784,56 +1784,69 @@ struct WalkerArgs {
     unsigned long long wperm;   // nibble k = the tile wave k evaluates (identity: 0xFEDCBA9876543210): the host's deal of the tiles to the
                            // waves by estimated cost (capi.hip: vp_add_instrument, walker_perm_for).  Tile sums still meet in LDS by
                            // TILE index, so results do not depend on it
-    // Pre-armed launch (arm_dev != NULL; capi.hip: vp_lnprob_batch): the launch is ON the GPU before its batch exists.  Its waves
-    // do everything that does not need theta (kernel arguments, pixel loads, table staging) and then wait: wave 0 of workgroup 0
-    // polls the host's word arm_host[0] (pinned host memory; (arm_seq << 2) | code, code 1 = the batch is in place, 2 = leave)
-    // and passes the decision on through arm_dev (device memory, agent scope), which the record waves of every other workgroup
-    // poll.  The wait is bounded (arm_ticks of the 100 MHz clock): on expiry the poller says so in arm_host[16] and everyone
-    // leaves without having written anything.  ONE wave decides, so a launch either runs for the whole batch or not at all.
-    const unsigned int* arm_host;
-    unsigned int* arm_dev;
+    // Pre-armed launch (arm_slots != NULL; capi.hip: vp_lnprob_batch): the launch is ON the GPU before its batch exists.  Its waves
+    // do everything that does not need theta (kernel arguments, pixel loads, table staging) and then wait for the HOST TO PUSH the
+    // batch: arm_slots is fine-grained device memory the CPU writes through the PCIe BAR, one slot of arm_slot_doubles (a
+    // multiple of 8: whole 64-byte lines) per workgroup -- the walker's theta row, then, in the slot's last 8 bytes and written
+    // last, (arm_seq << 2) | code (code 1 = the row is in place, 2 = leave).  Every workgroup polls ITS OWN slot in local memory:
+    // no read over PCIe, no word that a thousand waves share.  The wait is bounded (arm_ticks of the 100 MHz clock, looked at by
+    // wave 0 of workgroup 0): on expiry that wave tells every slot to leave and the host (arm_host[ARM_EXPIRED_WORD], pinned host
+    // memory); should the host's rows arrive at that very moment some workgroups run and some leave -- the host sees the expiry
+    // word, lets the launch drain and starts the batch again the ordinary way (host_wait).
+    const double* arm_slots;
+    unsigned int* arm_host;
     unsigned int arm_seq;
     int arm_ticks;
+    int arm_slot_doubles;
 };
 
 constexpr int ARM_GO = 1, ARM_LEAVE = 2;
-constexpr int ARM_DEV_WORDS = 64, ARM_DEV_STRIDE = 16;         // the decision in device memory: 64 copies, 64 bytes apart
 constexpr int ARM_EXPIRED_WORD = 16, ARM_STUCK_WORD = 32;      // (in units of 4 bytes: separate cache lines of the host block)
-// (wave-uniform) the decision for this launch
-__device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int lane) {
-    unsigned int v = 0;
-    if (w == 0 && wid == 0) {
-        const long long t0 = wall_clock64();
-        int code = ARM_LEAVE;
-        // (one read at a time: a PCIe round trip of 1.3-1.9 us each.  Four in flight, a new one every 0.35 us, were built and
-        //  measured: the reads still in flight when the word comes have to be waited for before the wave goes on, which costs
-        //  what the finer sampling gains -- profiles/r04_notes.md)
-        for (int spins = 0;; ++spins) {
-            v = __hip_atomic_load(A.arm_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((v >> 2) == A.arm_seq) { code = (int)(v & 3u); break; }
-            if (wall_clock64() - t0 > (long long)A.arm_ticks || spins > (1 << 20)) {     // (the count: should the clock ever stand still)
-                if (lane == 0) __hip_atomic_store(const_cast<unsigned int*>(A.arm_host) + ARM_EXPIRED_WORD, A.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        code = __builtin_amdgcn_readfirstlane(code);
-        // (ARM_DEV_WORDS copies, a cache line each: a thousand waves polling ONE word queue up behind each other -- and this store
-        //  behind them)
-        __hip_atomic_store(A.arm_dev + ARM_DEV_STRIDE * (lane & (ARM_DEV_WORDS - 1)), (A.arm_seq << 2) | (unsigned int)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return code;
-    }
-    const unsigned int* mine = A.arm_dev + ARM_DEV_STRIDE * ((2 * w + wid) & (ARM_DEV_WORDS - 1));
+// (wave-uniform) the decision for this workgroup; on ARM_GO `thv` holds the theta row across the lanes (lane >= D: the last parameter)
+__device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int lane, double& thv) {
+    const int n = A.arm_slot_doubles;
+    const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(A.arm_slots) + (size_t)w * n;
+    const bool keeper = w == 0 && wid == 0;          // the one wave that looks at the clock
+    const long long t0 = keeper ? wall_clock64() : 0ll;
+    const int dl = min(lane, A.D - 1);
     for (int spins = 0;; ++spins) {
-        v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((v >> 2) == A.arm_seq) break;
-        if (spins > SYNC_SPIN_LIMIT) {           // (workgroup 0 decides within arm_ticks: never met; the host relaunches the batch)
-            if (lane == 0) __hip_atomic_store(const_cast<unsigned int*>(A.arm_host) + ARM_STUCK_WORD, A.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long flag, row;
+        if (n == 8) {
+            // the whole slot is one 64-byte line: ONE request brings the row and the word behind it (lane 63 asks for the word)
+            row = __hip_atomic_load(slot + (lane == 63 ? 7 : dl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            flag = __builtin_amdgcn_readlane((unsigned int)row, 63) | ((unsigned long long)__builtin_amdgcn_readlane((unsigned int)(row >> 32), 63) << 32);
+        } else {
+            flag = __hip_atomic_load(slot + n - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            flag = __builtin_amdgcn_readfirstlane((unsigned int)flag) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(flag >> 32)) << 32);
+            row = 0ull;
+        }
+        if ((unsigned int)(flag >> 2) == A.arm_seq) {
+            const int code = (int)(flag & 3ull);
+            if (code == ARM_GO) {
+                // (several lines: the word was written behind a store fence, the row is read again now that it has been seen)
+                if (n != 8) row = __hip_atomic_load(slot + dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else if (A.D < 64) {
+                    const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)row, 62), hi = __builtin_amdgcn_readlane((unsigned int)(row >> 32), 62);
+                    if (lane == 63) row = lo | ((unsigned long long)hi << 32);       // (lane 63 held the word; lane 62 holds the last parameter)
+                }
+                thv = __longlong_as_double((long long)row);
+            }
+            return code;
+        }
+        if (keeper) {
+            if (wall_clock64() - t0 > (long long)A.arm_ticks || spins > (1 << 22)) {     // (the count: should the clock ever stand still)
+                const unsigned long long leave = ((unsigned long long)A.arm_seq << 2) | (unsigned long long)ARM_LEAVE;
+                unsigned long long* all = reinterpret_cast<unsigned long long*>(const_cast<double*>(A.arm_slots));
+                for (int i = lane; i < (int)gridDim.x; i += 64) __hip_atomic_store(all + (size_t)i * n + n - 1, leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane == 0) __hip_atomic_store(A.arm_host + ARM_EXPIRED_WORD, A.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return ARM_LEAVE;
+            }
+        } else if (spins > SYNC_SPIN_LIMIT) {           // (workgroup 0 speaks within arm_ticks: never met; the host starts the batch again)
+            if (lane == 0) __hip_atomic_store(A.arm_host + ARM_STUCK_WORD, A.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return ARM_LEAVE;
         }
         __builtin_amdgcn_s_sleep(2);
     }
-    return __builtin_amdgcn_readfirstlane((int)(v & 3u));
 }
 
 // Where a walker's lnprob goes (one thread per workgroup): the batch's output vector, and -- direct-write gather of a
@@ -1949,16 +1962,15 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             stash[68 + lane] = thv;
         }
     } else {
-        if (A.arm_dev) {
-            // pre-armed launch: the waves that need theta before the workgroup's barrier wait for the batch; the others go on
+        if (A.arm_slots) {
+            // pre-armed launch: the waves that need theta before the workgroup's barrier wait for the host to push it; the others go on
             const bool theta_wave = wid < 1 + ((T.L + 3) >> 2) + (CLUSTERS ? ((T.NCm + 63) >> 6) : 0);
             thv = 0.0;
             if (theta_wave) {
-                arm_code = arm_wait(A, w, wid, lane);
+                arm_code = arm_wait(A, w, wid, lane, thv);
 #ifdef VP_STAMPS
                 rt_go = wall_clock64();
 #endif
-                if (arm_code == ARM_GO) thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
             }
         } else
         thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
@@ -1995,7 +2007,8 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             prep_record_lanes(thv, T, (task - 1) * 4, lcw, lane);
         } else if (CLUSTERS) {
             const int k = (task - 1 - ngrp) * 64 + lane;
-            if (k < T.NCm) prep_cluster(A.theta + (size_t)w * A.D, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
+            const double* trow = A.arm_slots ? A.arm_slots + (size_t)w * A.arm_slot_doubles : A.theta + (size_t)w * A.D;
+            if (k < T.NCm) prep_cluster(trow, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
         }
     }
     VP_STAMP(10);

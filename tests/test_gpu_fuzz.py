@@ -361,6 +361,12 @@ def test_several_instruments_in_one_walker_launch(n_inst):
             e.add_instrument(wave, flux, oi.inv_sigma2, oi.log_inv_sigma2, **data.engine_kwargs())
         got = e.lnprob(thetas)
         assert e.last_launch_kind == "walker"
+        # the same launch left waiting on the GPU for the next call's theta (pre-armed: walker_kernel2 / walker_kernel4 too)
+        e.set_option("prearm", 1)
+        for _ in range(6):
+            np.testing.assert_array_equal(e.lnprob(thetas), got)
+        assert e.prearm_counts["used"] >= 5 and e.last_launch_kind == "walker"
+        e.set_option("prearm", -1)
         e.set_option("walker", 0); e.set_option("geom", 0); e.set_option("finalize", 0); e.set_option("tile_multi", 0)
         launches = e.lnprob(thetas)
         assert e.last_launch_kind == "tiles"
