@@ -211,6 +211,7 @@ struct vp_ctx {
         uint32_t seq_inflight = 0;
         bool have_last = false;       // last_return is set
         std::chrono::steady_clock::time_point last_return;
+        int misses = 0;               // consecutive launches that expired although their batch had been pushed
         int64_t used = 0, expired = 0, cancelled = 0;     // (vp_prearm_counts)
     } arm;
     bool sentinel_unsafe = false;    // some static input (bounds, spectra, line tables, taps) carries the sentinel's NaN payload
@@ -1635,11 +1636,14 @@ static int host_wait(vp_ctx* c) {
 #endif
                 ++i;
             }
-            if (i == W) { VP_HSTAMP(3); return VP_OK; }
+            if (i == W) { VP_HSTAMP(3); if (c->arm.inflight) c->arm.misses = 0; return VP_OK; }
             __builtin_ia32_pause();
             if (c->arm.inflight && (spins & 63u) == 63u &&
                 __atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) == c->arm.seq_inflight) {
                 ++c->arm.expired; --c->arm.used;
+                // (the go words were on their way and the launch still gave up: once is a caller that arrived at the last moment;
+                //  three times in a row is a system where the pushes do not reach the launch in time -- no more pre-armed launches)
+                if (++c->arm.misses >= 3) c->arm.bar = 0;
                 int rc = relaunch();
                 if (rc) return rc;
             }
@@ -1653,6 +1657,7 @@ static int host_wait(vp_ctx* c) {
             bool missing = false;
             for (int k = 0; k < W; ++k) missing |= __atomic_load_n(o + k, __ATOMIC_ACQUIRE) == VP_SENTINEL_BITS;
             if (missing) {
+                c->arm.bar = 0;
                 int rc = relaunch();
                 if (rc) return rc;
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
