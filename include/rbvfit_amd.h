@@ -96,7 +96,7 @@ int vp_update_spectrum(vp_ctx* ctx, int inst, const double* flux, const double* 
  * each is written exactly once; inputs carrying that payload make the call wait on a stream-written completion word instead):
  * `out` is complete when it returns, as with any synchronous call.
  * Pre-armed launches (option "prearm": -1 default, 0 never, 1 always; "prearm_us", default 1000): for batches that are one
- * walker_kernel launch, a call that came within prearm_us / 2 of the previous call's return leaves the launch for the NEXT batch
+ * walker_kernel launch, a call of the previous call's shape that came within prearm_us / 2 of its return leaves the launch for the NEXT batch
  * of this shape on the GPU.  It has done everything that does not depend on theta and waits -- at most prearm_us microseconds,
  * holding its compute units -- for the host to stage that batch; the next call then costs no launch: it copies theta, sets a
  * word in pinned memory and waits for the rows.  Every other entry point of the context (and vp_ctx_destroy) sends a waiting

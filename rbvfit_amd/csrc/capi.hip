@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cerrno>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <chrono>
 #include <thread>
 #include <cmath>
@@ -210,6 +213,7 @@ struct vp_ctx {
         bool inflight = false;        // the batch host_wait is waiting for was started through a pre-armed launch (seq_inflight)
         uint32_t seq_inflight = 0;
         bool have_last = false;       // last_return is set
+        int last_W = -1;              // rows of the previous vp_lnprob_batch call
         std::chrono::steady_clock::time_point last_return;
         int misses = 0;               // consecutive launches that expired although their batch had been pushed
         int64_t used = 0, expired = 0, cancelled = 0;     // (vp_prearm_counts)
@@ -518,7 +522,7 @@ bool walker_applies(const vp_ctx* c, int W) {
 
 // (clusters: without their multipole records the members are ordinary lines -- a few more wing evaluations per pass
 // against a cluster preparation chain inside every workgroup)
-template <bool SAMPLER>
+template <bool SAMPLER, bool ARMED = false>
 void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::StretchArgs& st, hipStream_t s) {
     const Instrument& in = c->inst[0];
     const dim3 grid(W), block(64 * walker_tiles(c));
@@ -541,17 +545,17 @@ void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::Stre
         for (size_t k = c->inst.size(); k < 4; ++k) tb.t[k - 1] = tsum;        // (no tiles)
         const bool fast = in.dev.method == VP_VOIGT_FAST;
         if (c->inst.size() == 2) {
-            if (fast) hipLaunchKernelGGL((vp::walker_kernel2<1, SAMPLER>), grid, block, lds, s, dk[0], dk[1], tb, t0, a, st);
-            else hipLaunchKernelGGL((vp::walker_kernel2<0, SAMPLER>), grid, block, lds, s, dk[0], dk[1], tb, t0, a, st);
+            if (fast) hipLaunchKernelGGL((vp::walker_kernel2<1, SAMPLER, ARMED>), grid, block, lds, s, dk[0], dk[1], tb, t0, a, st);
+            else hipLaunchKernelGGL((vp::walker_kernel2<0, SAMPLER, ARMED>), grid, block, lds, s, dk[0], dk[1], tb, t0, a, st);
         } else {
-            if (fast) hipLaunchKernelGGL((vp::walker_kernel4<1, SAMPLER>), grid, block, lds, s, dk[0], dk[1], dk[2], dk[3], tb, t0, a, st);
-            else hipLaunchKernelGGL((vp::walker_kernel4<0, SAMPLER>), grid, block, lds, s, dk[0], dk[1], dk[2], dk[3], tb, t0, a, st);
+            if (fast) hipLaunchKernelGGL((vp::walker_kernel4<1, SAMPLER, ARMED>), grid, block, lds, s, dk[0], dk[1], dk[2], dk[3], tb, t0, a, st);
+            else hipLaunchKernelGGL((vp::walker_kernel4<0, SAMPLER, ARMED>), grid, block, lds, s, dk[0], dk[1], dk[2], dk[3], tb, t0, a, st);
         }
         return;
     }
-    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, SAMPLER>), grid, block, lds, s, d0, t0, a, st);
-    else if (keep_clusters) hipLaunchKernelGGL((vp::walker_kernel<0, true, false>), grid, block, lds, s, d0, t0, a, st);
-    else hipLaunchKernelGGL((vp::walker_kernel<0, false, SAMPLER>), grid, block, lds, s, d0, t0, a, st);
+    if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, SAMPLER, ARMED>), grid, block, lds, s, d0, t0, a, st);
+    else if (keep_clusters) hipLaunchKernelGGL((vp::walker_kernel<0, true, false, ARMED>), grid, block, lds, s, d0, t0, a, st);
+    else hipLaunchKernelGGL((vp::walker_kernel<0, false, SAMPLER, ARMED>), grid, block, lds, s, d0, t0, a, st);
 }
 
 // which deal of tiles to waves a walker launch of W workgroups gets (Tuning::walker_perm)
@@ -589,7 +593,8 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     }
     vp::StretchArgs st{};
     if (gather) st.rep = *gather;            // (the plain form's only use of the sampler arguments: where the results go)
-    launch_walker_any<false>(c, W, a, st, s);
+    if (armed) launch_walker_any<false, true>(c, W, a, st, s);
+    else launch_walker_any<false>(c, W, a, st, s);
 }
 
 // One stretch-move half-step of the active half (nS walkers) as ONE launch: proposal, lnprob and accept/reject inside
@@ -875,6 +880,15 @@ int prearm_launch(vp_ctx* c, int W) {
         }
         HIP_TRY(c, hipMemset(c->arm.slots, 0, bytes));
         HIP_TRY(c, hipDeviceSynchronize());
+        {   // is the allocation really in this process's address space?  (asked of the kernel, not found out by a fault)
+            const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE), a0 = (uintptr_t)c->arm.slots & ~(pg - 1);
+            unsigned char vec[1];
+            if (mincore((void*)a0, 1, vec) != 0 && errno == ENOMEM) {
+                (void)hipFree(c->arm.slots);
+                c->arm.slots = nullptr; c->arm.bar = 0;
+                return VP_OK;
+            }
+        }
         c->arm.slot_rows = W;
         c->arm.slot_doubles = n;
     }
@@ -888,6 +902,31 @@ int prearm_launch(vp_ctx* c, int W) {
     c->arm.live_stream = s;
     c->arm.W = W;
     return VP_OK;
+}
+// Contexts alive in this process: a program that ends without vp_ctx_destroy must not leave a launch waiting on the GPU while the
+// runtime is taken down under it -- at exit every waiting launch is told to leave (CPU stores into its slots, no HIP call).
+std::mutex g_ctx_mu;
+std::vector<vp_ctx*> g_ctxs;
+void prearm_leave_all_at_exit() {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    bool any = false;
+    for (vp_ctx* c : g_ctxs)
+        if (c->mu.try_lock()) {
+            any |= c->arm.live;
+            prearm_cancel(c);
+            c->mu.unlock();
+        }
+    if (any) std::this_thread::sleep_for(std::chrono::microseconds(100));      // (a workgroup polls its slot every ~0.5 us)
+}
+void ctx_register(vp_ctx* c) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    static bool hooked = false;
+    if (!hooked) { std::atexit(prearm_leave_all_at_exit); hooked = true; }     // (behind the HIP runtime's own handlers: runs before them)
+    g_ctxs.push_back(c);
+}
+void ctx_unregister(vp_ctx* c) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end());
 }
 struct CtxGuard {                 // every entry but vp_lnprob_batch itself: lock the context and send a waiting launch away
     std::lock_guard<std::mutex> g;
@@ -955,6 +994,7 @@ int vp_ctx_create(vp_ctx** out, int device_id) {
                           (const void*)vp::tile_kernel<1, 2, false>})
         (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_limit);
     (void)hipGetLastError();
+    ctx_register(c);
     *out = c;
     return VP_OK;
 }
@@ -987,6 +1027,7 @@ static void gather_release(vp_ctx* c) {
 
 int vp_ctx_destroy(vp_ctx* c) {
     if (!c) return VP_OK;
+    ctx_unregister(c);
     { std::lock_guard<std::mutex> g(c->mu); prearm_cancel(c); }
     hipSetDevice(c->device);
     hipDeviceSynchronize();
@@ -1698,8 +1739,9 @@ int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
     // pre-arm the next call's launch?  (prearm = -1: when this call came quickly behind the last one's return -- a sampler's loop)
     int arm_next = 0;
     if (c->tune.prearm > 0) arm_next = 1;
-    else if (c->tune.prearm < 0 && c->arm.have_last)
+    else if (c->tune.prearm < 0 && c->arm.have_last && c->arm.last_W == W)      // (ragged batches -- a slice sampler's rounds -- never arm)
         arm_next = std::chrono::steady_clock::now() - c->arm.last_return < std::chrono::microseconds(std::max(1, c->tune.prearm_us / 2)) ? 1 : 0;
+    c->arm.last_W = W;
     if ((rc = lnprob_host_begin(c, W, D, theta, arm_next))) return rc;
     rc = lnprob_host_end(c, W, D, out);
     c->arm.inflight = false;

@@ -1883,7 +1883,8 @@ __device__ __forceinline__ void walker_result(const WalkerArgs& A, const Replica
 // tiles of instrument k, Ik its geometry and spectrum, tb.slw[k-1] its weight constant; the tile sums are added per
 // instrument, in order, as finalize_kernel does.
 struct WalkerMore { int t[3]; double slw[3]; };
-template <int METHOD, bool CLUSTERS, bool SAMPLER, int NI>   // CLUSTERS: the instrument has multipole cluster records (their
+template <int METHOD, bool CLUSTERS, bool SAMPLER, int NI, bool ARMED = false>   // ARMED: pre-armed launch (WalkerArgs::arm_*; an instance of
+                                       // its own, so that the ordinary launch's entry is compiled without the wait).  CLUSTERS: the instrument has multipole cluster records (their
                                        // preparation needs more registers than the tile work and spills to scratch;
                                        // kept out of the plain instance).  SAMPLER: stretch-move half-step (StretchArgs)
 #ifndef VP_WALKER_WPE
@@ -1962,7 +1963,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             stash[68 + lane] = thv;
         }
     } else {
-        if (A.arm_slots) {
+        if (ARMED) {
             // pre-armed launch: the waves that need theta before the workgroup's barrier wait for the host to push it; the others go on
             const bool theta_wave = wid < 1 + ((T.L + 3) >> 2) + (CLUSTERS ? ((T.NCm + 63) >> 6) : 0);
             thv = 0.0;
@@ -1995,7 +1996,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     const int hint_v = METHOD == 0 ? I.core_hint[lt] : 0;
     const int ngrp = (T.L + 3) >> 2, ncl = CLUSTERS ? ((T.NCm + 63) >> 6) : 0;
     const int ntask = 1 + ngrp + ncl;              // task 0: box prior; then line groups; then cluster records
-    if (!SAMPLER && arm_code != ARM_GO) {
+    if (ARMED && arm_code != ARM_GO) {
         if (tid == 0) red[nw] = 2.0;                  // (pre-armed launch told to leave: nobody evaluates or writes anything)
     } else
     for (int task = wid; task < ntask; task += nw) {
@@ -2007,7 +2008,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             prep_record_lanes(thv, T, (task - 1) * 4, lcw, lane);
         } else if (CLUSTERS) {
             const int k = (task - 1 - ngrp) * 64 + lane;
-            const double* trow = A.arm_slots ? A.arm_slots + (size_t)w * A.arm_slot_doubles : A.theta + (size_t)w * A.D;
+            const double* trow = ARMED ? A.arm_slots + (size_t)w * A.arm_slot_doubles : A.theta + (size_t)w * A.D;
             if (k < T.NCm) prep_cluster(trow, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
         }
     }
@@ -2039,7 +2040,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     if (daw_ready && A.prio) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
 #endif
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
-    if (!SAMPLER && red[nw] == 2.0) return;
+    if (ARMED && red[nw] == 2.0) return;
     if (oobw && !SAMPLER) {
         if (tid == 0) walker_result(A, S.rep, w, -__builtin_inf());
         return;
@@ -2117,19 +2118,19 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     }
 }
 
-template <int METHOD, bool CLUSTERS, bool SAMPLER>
+template <int METHOD, bool CLUSTERS, bool SAMPLER, bool ARMED = false>
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A, StretchArgs S) {
-    walker_body<METHOD, CLUSTERS, SAMPLER, 1>(I, I, I, I, WalkerMore{}, T, A, S);
+    walker_body<METHOD, CLUSTERS, SAMPLER, 1, ARMED>(I, I, I, I, WalkerMore{}, T, A, S);
 }
-template <int METHOD, bool SAMPLER>
+template <int METHOD, bool SAMPLER, bool ARMED = false>
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel2(InstDev I, InstDev I1, WalkerMore tb, LinesDev T, WalkerArgs A,
                                                                                    StretchArgs S) {
-    walker_body<METHOD, false, SAMPLER, 2>(I, I1, I1, I1, tb, T, A, S);
+    walker_body<METHOD, false, SAMPLER, 2, ARMED>(I, I1, I1, I1, tb, T, A, S);
 }
-template <int METHOD, bool SAMPLER>      // three or four instruments
+template <int METHOD, bool SAMPLER, bool ARMED = false>      // three or four instruments
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel4(InstDev I, InstDev I1, InstDev I2, InstDev I3, WalkerMore tb,
                                                                                    LinesDev T, WalkerArgs A, StretchArgs S) {
-    walker_body<METHOD, false, SAMPLER, 4>(I, I1, I2, I3, tb, T, A, S);
+    walker_body<METHOD, false, SAMPLER, 4, ARMED>(I, I1, I2, I3, tb, T, A, S);
 }
 
 // Final reduction as a launch of its own (one lane per walker), used for batches so large that the two
