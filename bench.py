@@ -534,7 +534,7 @@ def rank_main(args):
         pr = eng.profile_read()
         eng.profile_enable(False)
         kind = eng.last_launch_kind
-        kernel_name = {"walker": "vp::walker_kernel<0, false, false>", "tiles+farfield": "vp::tile_kernel<0, 0, false, true>"}.get(
+        kernel_name = {"walker": "vp::walker_kernel<0, false, false, false>", "tiles+farfield": "vp::tile_kernel1<0, true>"}.get(
             kind, "vp::tile_kernel<0, 0, false, false>")
         # Per-launch event pairs put record gaps (and, between dependent kernels, extra serialisation) into every
         # interval -- 8-10 % on a 200-700 us kernel, more on a 30 us one -- so they are only used for the SHARE of the
@@ -565,6 +565,7 @@ def rank_main(args):
                 pm = json.load(open(cand))
                 if pm.get("config") == args.config and pm.get("walkers_per_gpu") == W:
                     traffic, traffic_src = pm["tile_kernel_hbm_bytes_per_launch"], os.path.basename(cand)
+                    kernel_name = pm.get("kernel", kernel_name)       # (the name rocprofv3 gave the dominant kernel of this command)
                     break
         except Exception:
             pass

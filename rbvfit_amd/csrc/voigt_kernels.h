@@ -1963,17 +1963,8 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             stash[68 + lane] = thv;
         }
     } else {
-        if (ARMED) {
-            // pre-armed launch: the waves that need theta before the workgroup's barrier wait for the host to push it; the others go on
-            const bool theta_wave = wid < 1 + ((T.L + 3) >> 2) + (CLUSTERS ? ((T.NCm + 63) >> 6) : 0);
-            thv = 0.0;
-            if (theta_wave) {
-                arm_code = arm_wait(A, w, wid, lane, thv);
-#ifdef VP_STAMPS
-                rt_go = wall_clock64();
-#endif
-            }
-        } else
+        if (ARMED) thv = 0.0;          // (pre-armed launch: theta comes further down, behind everything that does not need it)
+        else
         thv = A.theta[(size_t)w * A.D + min(lane, A.D - 1)];
         // direct-write gather (vp_gather_*): the batch before this one has arrived here from every rank before this one
         // computes -- the dependency of an ensemble step on the whole ensemble's lnprob, as a blocking all-gather states it
@@ -1996,33 +1987,68 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     const int hint_v = METHOD == 0 ? I.core_hint[lt] : 0;
     const int ngrp = (T.L + 3) >> 2, ncl = CLUSTERS ? ((T.NCm + 63) >> 6) : 0;
     const int ntask = 1 + ngrp + ncl;              // task 0: box prior; then line groups; then cluster records
-    if (ARMED && arm_code != ARM_GO) {
-        if (tid == 0) red[nw] = 2.0;                  // (pre-armed launch told to leave: nobody evaluates or writes anything)
-    } else
-    for (int task = wid; task < ntask; task += nw) {
-        if (task == 0) {
-            const bool oob = lane < A.D && ((thv < A.lb[min(lane, A.D - 1)]) || (thv > A.ub[min(lane, A.D - 1)]));
-            const bool any = __ballot(oob) != 0ull;
-            if (lane == 0) red[nw] = any ? 1.0 : 0.0;
-        } else if (task <= ngrp) {
-            prep_record_lanes(thv, T, (task - 1) * 4, lcw, lane);
-        } else if (CLUSTERS) {
-            const int k = (task - 1 - ngrp) * 64 + lane;
-            const double* trow = ARMED ? A.arm_slots + (size_t)w * A.arm_slot_doubles : A.theta + (size_t)w * A.D;
-            if (k < T.NCm) prep_cluster(trow, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
+    auto run_tasks = [&](double th, bool rehearsal) {
+        for (int task = wid; task < ntask; task += nw) {
+            if (task == 0) {
+                const bool oob = lane < A.D && ((th < A.lb[min(lane, A.D - 1)]) || (th > A.ub[min(lane, A.D - 1)]));
+                const bool any = __ballot(oob) != 0ull;
+                if (lane == 0) red[nw] = any ? 1.0 : 0.0;
+            } else if (task <= ngrp) {
+                prep_record_lanes(th, T, (task - 1) * 4, lcw, lane);
+            } else if (CLUSTERS && !rehearsal) {
+                const int k = (task - 1 - ngrp) * 64 + lane;
+                const double* trow = ARMED ? A.arm_slots + (size_t)w * A.arm_slot_doubles : A.theta + (size_t)w * A.D;
+                if (k < T.NCm) prep_cluster(trow, T, k, lcw + (size_t)(T.L + k) * LC_STRIDE);
+            }
         }
+    };
+    TilePre pre;
+    bool daw_ready;
+    if (ARMED) {
+        // Pre-armed launch: what does not need theta FIRST -- the wave's exp table, the Dawson table where the tile met line cores
+        // before, the pixels of the waves that form no records -- then the waves that form the records wait for the host's push.  While they wait
+        // they have rehearsed: the record code has run once on the middle of the prior box (same instructions, same tables,
+        // same workspace rows, overwritten by the real pass), so that the pass that counts finds its instructions, its
+        // constants and its translations in the caches.
+        // (the record waves ask for their pixels behind their records, as in the ordinary launch: held across the record code
+        //  the preloaded registers cost it spills)
+        if (lane < EXP_LDS_DOUBLES) fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = exp2_eighth(lane);
+        daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(hint_v) != 0;
+        if (daw_ready) dawson_to_lds(fl + I.span + FL_PAD + 4, lane, 64);
+        if (wid < ntask) {
+#pragma nounroll
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 0) {
+                    const int dl = min(lane, A.D - 1);
+                    thv = 0.5 * (A.lb[dl] + A.ub[dl]);
+                } else {
+                    arm_code = arm_wait(A, w, wid, lane, thv);
+#ifdef VP_STAMPS
+                    rt_go = wall_clock64();
+#endif
+                    if (arm_code != ARM_GO) break;
+                }
+                run_tasks(thv, pass == 0);
+            }
+            if (arm_code != ARM_GO && tid == 0) red[nw] = 2.0;      // (told to leave: nobody evaluates or writes anything)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        VP_STAMP(10);
+        pre = tile_preload(I, p0, nout, lane);
+    } else {
+        run_tasks(thv, false);
+        VP_STAMP(10);
+        // only the waves that stored records drain (s_waitcnt vmcnt(0): the write-through L1 has handed the stores to L2), and
+        // before they ask for their own pixels -- the other waves' loads stay in flight across the barrier (256 walkers 16.05 ->
+        // 15.9 us, 512 unchanged: there the record wave itself is the last to arrive)
+        if (wid < ntask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
+        if (lane < EXP_LDS_DOUBLES) fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = exp2_eighth(lane);   // the wave's exp table,
+                                                                               // staged while it waits for the records anyway
+        // ... and the Dawson table where the tile met line cores before (1.2 us between phase A and phase B otherwise)
+        daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(hint_v) != 0;
+        if (daw_ready) dawson_to_lds(fl + I.span + FL_PAD + 4, lane, 64);
     }
-    VP_STAMP(10);
-    // only the waves that stored records drain (s_waitcnt vmcnt(0): the write-through L1 has handed the stores to L2), and
-    // before they ask for their own pixels -- the other waves' loads stay in flight across the barrier (256 walkers 16.05 ->
-    // 15.9 us, 512 unchanged: there the record wave itself is the last to arrive)
-    if (wid < ntask) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const TilePre pre = tile_preload(I, p0, nout, lane);     // in flight while the stores drain
-    if (lane < EXP_LDS_DOUBLES) fl[I.span + FL_PAD + 4 + DAW_LDS_DOUBLES + lane] = exp2_eighth(lane);   // the wave's exp table,
-                                                                           // staged while it waits for the records anyway
-    // ... and the Dawson table where the tile met line cores before (1.2 us between phase A and phase B otherwise)
-    const bool daw_ready = METHOD == 0 && __builtin_amdgcn_readfirstlane(hint_v) != 0;
-    if (daw_ready) dawson_to_lds(fl + I.span + FL_PAD + 4, lane, 64);
     VP_STAMP(11);
     __syncthreads();
     VP_STAMP(1);
