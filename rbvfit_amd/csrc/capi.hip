@@ -89,6 +89,7 @@ struct Tuning {
                                 // between the caller's theta and the arithmetic.  -1: when the previous call came within prearm_us / 2 of the
                                 // one before returning (a sampler's loop), 0 never, 1 after every eligible call
     int prearm_us = 1000;       // how long a pre-armed launch waits for its batch before it leaves (the GPU is held meanwhile)
+    int stretch_mailbox = 1;    // ... with a walker's row, lnprob and version in one 64-byte line per buffer (D <= 6): 0 = separate arrays
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
                                 // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
@@ -104,7 +105,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
     VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
-    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0), VP_KNOB(walker_prio, "RBVFIT_AMD_WALKER_PRIO", 0), VP_KNOB(walker_perm_hex, "RBVFIT_AMD_WALKER_PERM_HEX", 1),
+    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(stretch_mailbox, "RBVFIT_AMD_STRETCH_MAILBOX", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0), VP_KNOB(walker_prio, "RBVFIT_AMD_WALKER_PRIO", 0), VP_KNOB(walker_perm_hex, "RBVFIT_AMD_WALKER_PERM_HEX", 1),
     VP_KNOB(prearm, "RBVFIT_AMD_PREARM", 0), VP_KNOB(prearm_us, "RBVFIT_AMD_PREARM_US", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
@@ -1877,7 +1878,8 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     const int half = W / 2;
     // device state: pos (W,D) | lp (W) | prop (half,D) | lp_new (half) | zz (half) | second buffer of pos, lp (overlapped half-steps) |
     //               chain chunk | nacc (W) | nanflag, timeout | versions (W)
-    const size_t nd_state = (size_t)W * D + W + (size_t)half * D + 2 * (size_t)half + (size_t)W * D + W;
+    //               mailbox lines 2 x W x 8 (overlapped half-steps with D <= 6: row, lnprob, version in one 64-byte line) |
+    const size_t nd_state = (size_t)W * D + W + (size_t)half * D + 2 * (size_t)half + (size_t)W * D + W + 8 + 2 * (size_t)W * 8;
     const size_t row = (size_t)W * (D + 1);                       // doubles stored per step
     size_t chunk = chain ? std::max<size_t>(1, std::min<size_t>((size_t)std::max(nsteps, 1), ((size_t)256 << 20) / (row * sizeof(double)))) : 0;
     const size_t bytes = (nd_state + chunk * row) * sizeof(double) + (size_t)W * sizeof(long long) + 64 + (size_t)W * sizeof(int);
@@ -1889,7 +1891,8 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     double* d_zz = d_lpnew + half;
     double* d_pos1 = d_zz + half;                                 // the rows' second buffer (overlapped half-steps)
     double* d_lp1 = d_pos1 + (size_t)W * D;
-    double* d_chain = d_lp1 + W;                                  // chunk * (W*D) then chunk * W
+    double* d_mail = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_lp1 + W) + 63) & ~(uintptr_t)63);    // 64-byte aligned lines
+    double* d_chain = d_mail + 2 * (size_t)W * 8;                 // chunk * (W*D) then chunk * W
     long long* d_nacc = reinterpret_cast<long long*>(d_chain + chunk * row);
     int* d_nan = reinterpret_cast<int*>(d_nacc + W);             // [0] NaN flag, [1] a device-side wait gave up
     int* d_ver = d_nan + 16;                                      // (W) versions
@@ -1934,6 +1937,23 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
                 hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ovl = false; }
         }
     }
+    // mailbox lines (StretchArgs::ovl == 2): row, lnprob and version of a walker in one 64-byte line per buffer, packed here
+    const bool mail = ovl && D <= 6 && c->tune.stretch_mailbox != 0;
+    std::vector<double> h_mail;
+    if (mail) {
+        h_mail.assign(2 * (size_t)W * 8, 0.0);
+        std::vector<double> lp0(W);
+        if (have_lnprob) std::memcpy(lp0.data(), lnprob, (size_t)W * sizeof(double));
+        else {
+            HIP_TRY(c, hipMemcpyAsync(lp0.data(), d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
+        for (int w = 0; w < W; ++w) {
+            std::memcpy(&h_mail[(size_t)w * 8], pos + (size_t)w * D, (size_t)D * sizeof(double));
+            h_mail[(size_t)w * 8 + 6] = lp0[w];                    // ([7]: version 0 = all-zero bits)
+        }
+        HIP_TRY(c, hipMemcpyAsync(d_mail, h_mail.data(), h_mail.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    }
     hipStream_t s2 = ovl ? c->stream2 : s;
     // (whatever way this call ends -- an error return from the middle of the loop included -- nothing of it is left running on the
     //  second stream when the context's mutex is released)
@@ -1958,9 +1978,9 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
                         // every walker has been updated k = done + it times when this step begins (the first half once more when
                         // h = 1): rows live in buffer (update count) & 1
                         const int k = done + it, t = 2 * k + h;
-                        double* pb[2] = {d_pos, d_pos1};
+                        double* pb[2] = {mail ? d_mail : d_pos, mail ? d_mail + (size_t)W * 8 : d_pos1};
                         double* lb2[2] = {d_lp, d_lp1};
-                        sa.ovl = 1; sa.need = t; sa.mine = t + 1; sa.ver = d_ver; sa.timeout = d_nan + 1;
+                        sa.ovl = mail ? 2 : 1; sa.need = t; sa.mine = t + 1; sa.ver = d_ver; sa.timeout = d_nan + 1;
                         sa.pos_x = pb[k & 1]; sa.lp_x = lb2[k & 1];
                         sa.pos_w = pb[(k + 1) & 1]; sa.lp_w = lb2[(k + 1) & 1];
                         sa.pos_c = pb[(h ? k + 1 : k) & 1];
@@ -2008,11 +2028,20 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     std::vector<long long> h_nacc(W);
     int h_flags[2] = {0, 0};
     // (overlapped half-steps: after nsteps updates the rows are in buffer nsteps & 1)
-    HIP_TRY(c, hipMemcpyAsync(pos, (ovl && (nsteps & 1)) ? d_pos1 : d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(lnprob, (ovl && (nsteps & 1)) ? d_lp1 : d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (mail) {
+        HIP_TRY(c, hipMemcpyAsync(h_mail.data(), d_mail + (size_t)(nsteps & 1) * W * 8, (size_t)W * 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(pos, (ovl && (nsteps & 1)) ? d_pos1 : d_pos, (size_t)W * D * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(lnprob, (ovl && (nsteps & 1)) ? d_lp1 : d_lp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(c, hipMemcpyAsync(h_nacc.data(), d_nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(h_flags, d_nan, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (mail)
+        for (int w = 0; w < W; ++w) {
+            std::memcpy(pos + (size_t)w * D, &h_mail[(size_t)w * 8], (size_t)D * sizeof(double));
+            lnprob[w] = h_mail[(size_t)w * 8 + 6];
+        }
     if (h_flags[1]) return fail(c, VP_EHIP, "vp_stretch_run: a workgroup's wait for its partner's half-step gave up (overlapped half-steps)");
     if (naccepted) for (int w = 0; w < W; ++w) naccepted[w] += (int64_t)h_nacc[w];
     if (h_flags[0]) return fail(c, VP_ENAN, "vp_stretch_run: Probability function returned NaN");

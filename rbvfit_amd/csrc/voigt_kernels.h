@@ -1761,7 +1761,9 @@ struct StretchArgs {
     // by side; a walker's workgroup waits for ITS partner alone -- ver[c0 + j] >= need, the partner's workgroup of the half-step
     // before publishes `mine` behind its row -- instead of the whole launch before it.  Everything a workgroup does before it
     // needs theta (kernel arguments, pixel loads, table staging) then runs under the previous half-step's arithmetic, and no
-    // kernel boundary lies on the chain of dependent half-steps.  Rows are double-buffered by the parity of the walker's update
+    // kernel boundary lies on the chain of dependent half-steps.  (ovl == 2, D <= 6: pos_x / pos_w / pos_c are arrays of 64-byte
+    // "mailbox" lines -- row, lnprob at [6], version at [7] -- and lp_x / lp_w / ver are not used: one load shows a partner's version
+    // AND its row.)  Rows are double-buffered by the parity of the walker's update
     // count, so that a late reader of the half-step before never meets this half-step's store: own row read from pos_x / lp_x,
     // partner from pos_c, the row of this half-step (moved or not) written to pos_w / lp_w.  `timeout`: a wait gave up.
     int ovl, need, mine;
@@ -1934,7 +1936,26 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         // (overlapped half-steps: only the waves that use the proposal before the workgroup's barrier -- prior, records, the
         //  accept step's operands -- wait for the partner; the others go on to their pixels and tables)
         const bool uses_theta = !S.ovl || wid < 1 + ((T.L + 3) >> 2) + (CLUSTERS ? ((T.NCm + 63) >> 6) : 0) || wid == nw - 1;
-        if (uses_theta) {
+        if (uses_theta && S.ovl == 2) {
+            // mailbox lines (D <= 6): a walker's row, its lnprob and its version in ONE 64-byte line per buffer -- the line that
+            // shows the partner's version also holds its row (the row was written, and acknowledged, before the version)
+            x = posX[(size_t)(S.s0 + w) * 8 + d];
+            const unsigned long long* line = reinterpret_cast<const unsigned long long*>(S.pos_c) + (size_t)(S.c0 + j) * 8;
+            for (int spins = 0;; ++spins) {
+                const unsigned long long v = __hip_atomic_load(line + (lane == 63 ? 7 : d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)__builtin_amdgcn_readlane((unsigned int)v, 63) >= S.need) {
+                    c = __longlong_as_double((long long)v);
+                    const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)v, 62), hi = __builtin_amdgcn_readlane((unsigned int)(v >> 32), 62);
+                    if (lane == 63) c = __longlong_as_double((long long)(lo | ((unsigned long long)hi << 32)));
+                    break;
+                }
+                if (spins > SYNC_SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(S.timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        } else if (uses_theta) {
             x = posX[(size_t)(S.s0 + w) * A.D + d];
             if (S.ovl) {
                 int spins = 0;
@@ -1955,7 +1976,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         // the records anyway: at the end of the workgroup's life it was ~2.5 us of Philox blocks, logarithms and a memory round
         // trip on wave 0 alone
         if (wid == nw - 1) {
-            const double lp_old = lpX[S.s0 + w];
+            const double lp_old = S.ovl == 2 ? posX[(size_t)(S.s0 + w) * 8 + 6] : lpX[S.s0 + w];
             const Philox4 r1 = draw(S.seed, S.step, S.half, S.s0 + w, 1u);
             const double lz = (double)(A.D - 1) * log(z), lu = log(u01(r1.v[0], r1.v[1]));
             if (lane == 0) { stash[0] = lz; stash[1] = lu; stash[2] = lp_old; }
@@ -2113,7 +2134,16 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             const double lnq = stash[0] + lnp - lp_old;
             accept = stash[1] < lnq;
         }
-        if (S.ovl) {
+        if (S.ovl == 2) {
+            unsigned long long* line = reinterpret_cast<unsigned long long*>(S.pos_w) + (size_t)ws * 8;
+            if (lane < A.D) __hip_atomic_store(line + lane, (unsigned long long)__double_as_longlong(accept ? y : x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(line + 6, (unsigned long long)__double_as_longlong(accept ? lnp : lp_old), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                __hip_atomic_store(line + 7, (unsigned long long)S.mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (accept) atomicAdd(reinterpret_cast<unsigned long long*>(S.nacc + ws), 1ull);     // (behind the version: nobody waits for it)
+            }
+        } else if (S.ovl) {
             // this half-step's row -- moved or not -- into the buffer the next half-steps read, then the walker's version:
             // agent-scope stores, drained before the version (the partner polls it with agent-scope loads and reads the row
             // the same way)
