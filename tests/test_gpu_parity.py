@@ -407,6 +407,19 @@ def test_prearmed_launches_change_nothing():
             while time.perf_counter() - t0 < (20 + (k % 61)) * 1e-6:
                 pass
             assert np.array_equal(eng.lnprob(batches[k % 6]), want[k % 6], equal_nan=True)
+    # more workgroups than the GPU holds at once (1024 walkers of 12 waves: the second round starts as the first one's leave)
+    big = np.tile(batches[0], (11, 1))[:1024].copy()
+    with engine_from_fixture(z) as ref:
+        ref.set_option("prearm", 0)
+        want_big = ref.lnprob(big)
+        kind = ref.last_launch_kind
+    with engine_from_fixture(z) as eng:
+        eng.set_option("prearm", 1)
+        for _ in range(10):
+            assert np.array_equal(eng.lnprob(big), want_big)
+        assert eng.last_launch_kind == kind
+        if kind == "walker":
+            assert eng.prearm_counts["used"] >= 8, eng.prearm_counts
     # by default (prearm = -1) a loop of calls arms, a lone call does not
     with engine_from_fixture(z) as eng:
         eng.set_option("walker", 1)
