@@ -929,9 +929,20 @@ void ctx_unregister(vp_ctx* c) {
     std::lock_guard<std::mutex> g(g_ctx_mu);
     g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end());
 }
+// A launch that waits holds its compute units: work of ANOTHER context of this process on the same GPU would sit behind it until it
+// expires.  Every entry point therefore sends the other contexts' waiting launches away first (one short lock when there are none).
+void prearm_cancel_others(vp_ctx* c) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    if (g_ctxs.size() < 2) return;
+    for (vp_ctx* o : g_ctxs)
+        if (o != c && o->device == c->device && o->mu.try_lock()) {       // (a context busy in a call of its own has no launch waiting)
+            prearm_cancel(o);
+            o->mu.unlock();
+        }
+}
 struct CtxGuard {                 // every entry but vp_lnprob_batch itself: lock the context and send a waiting launch away
     std::lock_guard<std::mutex> g;
-    explicit CtxGuard(vp_ctx* c) : g(c->mu) { prearm_cancel(c); }
+    explicit CtxGuard(vp_ctx* c) : g(c->mu) { prearm_cancel(c); prearm_cancel_others(c); }
 };
 
 // (called with c->mu held)
@@ -1737,6 +1748,7 @@ int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
 #ifdef VP_STAMPS
     g_host_t0 = std::chrono::steady_clock::now();
 #endif
+    prearm_cancel_others(c);
     // pre-arm the next call's launch?  (prearm = -1: when this call came quickly behind the last one's return -- a sampler's loop)
     int arm_next = 0;
     if (c->tune.prearm > 0) arm_next = 1;

@@ -420,6 +420,21 @@ def test_prearmed_launches_change_nothing():
         assert eng.last_launch_kind == kind
         if kind == "walker":
             assert eng.prearm_counts["used"] >= 8, eng.prearm_counts
+    # two contexts on one GPU, called in turn: a launch that waits holds its compute units, so each call sends the OTHER context's
+    # waiting launch away first -- nobody sits out the other's waiting time (1 ms by default)
+    with engine_from_fixture(z) as e1, engine_from_fixture(z) as e2:
+        for e in (e1, e2):
+            e.set_option("prearm", 1)
+            e.set_option("walker", 1)
+        for e in (e1, e2, e1, e2):
+            assert np.array_equal(e.lnprob(batches[0]), want[0])
+        t0 = time.perf_counter()
+        for k in range(100):
+            assert np.array_equal(e1.lnprob(batches[k % 6]), want[k % 6], equal_nan=True)
+            assert np.array_equal(e2.lnprob(batches[(k + 1) % 6]), want[(k + 1) % 6], equal_nan=True)
+        per_call = (time.perf_counter() - t0) / 200
+        assert per_call < 300e-6, per_call
+        assert e1.prearm_counts["cancelled"] >= 90 and e2.prearm_counts["cancelled"] >= 90
     # by default (prearm = -1) a loop of calls arms, a lone call does not
     with engine_from_fixture(z) as eng:
         eng.set_option("walker", 1)
