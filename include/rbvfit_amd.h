@@ -98,8 +98,9 @@ int vp_update_spectrum(vp_ctx* ctx, int inst, const double* flux, const double* 
  * Pre-armed launches (option "prearm": -1 default, 0 never, 1 always; "prearm_us", default 1000): for batches that are one
  * walker_kernel launch, a call of the previous call's shape that came within prearm_us / 2 of its return leaves the launch for the NEXT batch
  * of this shape on the GPU.  It has done everything that does not depend on theta and waits -- at most prearm_us microseconds,
- * holding its compute units -- for the host to stage that batch; the next call then costs no launch: it copies theta, sets a
- * word and waits for the rows.  Every other entry point of the context, every call on another context of this process on the same
+ * holding its compute units -- for the host to push that batch: the next call then costs no launch and no read over PCIe: it writes
+ * theta and a go word into the launch's slots in device memory through the PCIe BAR (GPUs without a large BAR: no pre-armed launches) and
+ * waits for the rows.  Every other entry point of the context, every call on another context of this process on the same
  * GPU, vp_ctx_destroy and process exit send a waiting launch away first; a launch that expired, or a batch of another shape, falls back to the ordinary launch.  Results do not
  * depend on which way a batch was started.  vp_prearm_counts reports how often each happened. */
 int vp_lnprob_batch(vp_ctx* ctx, int W, int D, const double* theta, double* out);
