@@ -174,7 +174,9 @@ int vp_voigt_h(vp_ctx* ctx, int na, const double* a, int nx, const double* x, do
  * "Probability function returned NaN" there.
  * Where a half-step is one launch and two half-ensembles of workgroups fit the GPU at once, consecutive half-steps are enqueued on
  * two streams of the context and overlap: a walker's workgroup waits (bounded; VP_EHIP if a wait gives up) for its partner's row
- * of the half-step before, not for that whole launch.  The chain does not depend on it (option "stretch_overlap": -1 / 0 / 1). */
+ * of the half-step before, not for that whole launch; with D <= 6 a walker's row, lnprob and version share one 64-byte line per
+ * buffer, so that the load which shows a partner's version also holds its row (option "stretch_mailbox": 1 / 0).  The chain does not
+ * depend on either (option "stretch_overlap": -1 / 0 / 1). */
 int vp_stretch_run(vp_ctx* ctx, int W, int D, double* pos, double* lnprob, int have_lnprob, int nsteps, double a,
                    uint64_t seed, uint64_t step0, double* chain, double* chain_lnprob, int64_t* naccepted);
 
