@@ -85,11 +85,13 @@ struct Tuning {
                                 // (every half-step behind the one before, one stream); 1 whenever the half-steps are one launch each
     int prearm = -1;            // vp_lnprob_batch, batches that are ONE walker_kernel launch: the launch for the NEXT call is put on the GPU
                                 // while this call's runs, waits there for its theta (WalkerArgs::arm_*) and starts the moment the host has
-                                // staged it -- no launch call, no command-processor latency and none of the kernel's theta-independent entry
-                                // between the caller's theta and the arithmetic.  -1: when the previous call came within prearm_us / 2 of the
+                                // pushed it into the launch's slots (device memory, written through the PCIe BAR) -- no launch call, no
+                                // command-processor latency, no read over PCIe and none of the kernel's theta-independent entry between the
+                                // caller's theta and the arithmetic.  -1: when the previous call came within prearm_us / 2 of the
                                 // one before returning (a sampler's loop), 0 never, 1 after every eligible call
     int prearm_us = 1000;       // how long a pre-armed launch waits for its batch before it leaves (the GPU is held meanwhile)
-    int stretch_mailbox = 1;    // ... with a walker's row, lnprob and version in one 64-byte line per buffer (D <= 6): 0 = separate arrays
+    int stretch_mailbox = 1;    // vp_stretch_run's overlapped half-steps (stretch_overlap) keep a walker's row, lnprob and version in one 64-byte
+                                // line per buffer where D <= 6 (StretchArgs::ovl = 2); 0 = separate arrays
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
                                 // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
@@ -1664,8 +1666,9 @@ static int host_wait(vp_ctx* c) {
         const int W = c->sentinel_W;
         const auto t0 = std::chrono::steady_clock::now();
         int i = 0;
-        // (a batch handed to a pre-armed launch: the launch may have given up waiting just before the go word came -- it says so,
-        //  has written nothing, and the batch is launched the ordinary way, after the launch armed behind it has been sent away)
+        // (a batch handed to a pre-armed launch: the launch may have given up waiting just as the rows and go words were on their way --
+        //  it says so; some of its workgroups may have met their rows and run.  The batch is then started again the ordinary way:
+        //  the launch armed behind it is sent away, the stream drains, the rows are set to the pattern again)
         auto relaunch = [&]() -> int {
             c->arm.inflight = false;
             prearm_cancel(c);
