@@ -783,7 +783,9 @@ def rank_main(args):
                                 "bench contract's definition, PCIe-inclusive rates are never `value`).  `value_host_entry`: the same batch through "
                                 "vp_lnprob_batch with host buffers -- what north_star's sampler loop and SURVEY 8(d)'s 'wall time around "
                                 "vp_lnprob_batch including H2D/D2H' describe (emcee vectorize=True, the INTEGRATION.md stub) --, timed over as "
-                                "many seconds; both are first-class numbers of this line",
+                                "many seconds, calls back to back as a sampler makes them (so the library's pre-armed launch of the next call "
+                                "is in play: host_entry_latency.prearm has the same loop without it and a caller with 100 us between calls); "
+                                "both are first-class numbers of this line",
             "seam_evals_per_sec": host_rate,
             "host_entry_evals_per_sec_pcie_inclusive": host_rate,
             "host_entry_latency": host_lat,
