@@ -177,7 +177,10 @@ struct vp_ctx {
     double* d_partial = nullptr; // (capW, total_tiles)
     int* d_flags = nullptr;      // (capW)
     unsigned int* d_ticket = nullptr;  // (capW) arrival counters of the fused final reduction
-    int* d_genflag = nullptr;    // (capW) walkers with lines outside the fast domain (per instrument pass)
+    int* d_genflag = nullptr;    // 2 x (capW) walkers with lines outside the fast domain (per instrument pass): two buffers in turn -- the
+                                 // record-preparation launch that fills one clears the other for the launch after it (genflag_acquire)
+    unsigned gen_seq = 0;
+    int gen_clean[2] = {0, 0};   // leading entries of each buffer known to be zero
     double* d_ff = nullptr;      // (capW x cap_ffblk, FF_STRIDE) far-field expansions, instrument after instrument
     int cap_ffblk = 0;
     std::vector<double> h_lb;    // host copy of the lower bounds
@@ -372,8 +375,9 @@ int ensure_workspace(vp_ctx* c, int W) {
     HIP_TRY(c, hipMemset(c->d_flags, 0, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMalloc((void**)&c->d_ticket, (size_t)newW * sizeof(unsigned int)));
     HIP_TRY(c, hipMemset(c->d_ticket, 0, (size_t)newW * sizeof(unsigned int)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_genflag, (size_t)newW * sizeof(int)));
-    HIP_TRY(c, hipMemset(c->d_genflag, 0, (size_t)newW * sizeof(int)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_genflag, 2 * (size_t)newW * sizeof(int)));
+    HIP_TRY(c, hipMemset(c->d_genflag, 0, 2 * (size_t)newW * sizeof(int)));
+    c->gen_clean[0] = c->gen_clean[1] = newW;
     c->capW = newW; c->capL = maxL; c->cap_tiles = c->total_tiles; c->cap_ffblk = ffblk;
     return VP_OK;
 }
@@ -440,8 +444,21 @@ size_t prof_mark(vp_ctx* c, hipStream_t s) {
 // the last-arriving tile workgroup of each walker performs the final reduction.
 // Record preparation launch: one lane per record, 64 records per wave (fewer per wave measured no
 // faster even at 512 walkers x 4 lines; the prep_rpw knob overrides for experiments).
+// The generic-path flags of a record-preparation launch: the buffer whose turn it is, zero in its first W entries (a memset only
+// where the launch before could not vouch for that), and the other buffer, which this launch clears for the next one.
+struct GenFlags { int* use; int* clear; };
+static int genflag_acquire(vp_ctx* c, int W, hipStream_t s, GenFlags* out) {
+    const int b = (int)(c->gen_seq & 1u), o = b ^ 1;
+    int* use = c->d_genflag + (size_t)b * c->capW;
+    if (c->gen_clean[b] < W) HIP_TRY(c, hipMemsetAsync(use, 0, (size_t)W * sizeof(int), s));
+    c->gen_clean[b] = 0;                                   // (written by this launch)
+    if (c->gen_clean[o] < W) c->gen_clean[o] = W;          // (cleared by this launch)
+    ++c->gen_seq;
+    *out = GenFlags{use, c->d_genflag + (size_t)o * c->capW};
+    return VP_OK;
+}
 static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_theta, int W, int do_flags, double* d_out,
-                        int* genflag, hipStream_t s) {
+                        int* genflag, hipStream_t s, int* genflag_clear = nullptr) {
     const long nline = (long)W * in.dev.L, ncl = (long)W * in.dev.NCm;
     const int rpw = std::max(1, std::min(64, c->tune.prep_rpw));
     vp::PrepGrid g;
@@ -457,7 +474,7 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
     // (direct-write gather: the pass's first launch -- the one that applies the box prior -- handshakes with the peers)
     const vp::Replicas rep = (c->gather_rep && do_flags) ? *c->gather_rep : vp::Replicas{};
     hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(g.nb_line + g.nb_cl + g.nb_flag), dim3(64), 0, s, d_theta, W, c->D,
-                       in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g, rep);
+                       in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g, rep, genflag_clear);
 }
 
 // walker_kernel: the whole batch in ONE launch (workgroup = walker, wave = tile).  Possible for a single
@@ -706,13 +723,15 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         }
     }
     bool ff_made = false;                            // this instrument's expansions came with the previous one's launch
+    GenFlags gf{c->d_genflag, nullptr};              // (the flags of the records in the workspace: shared by instruments that share those)
+    int rc_gf = VP_OK;
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
         const bool gen = in.needs_generic && in.dev.method == VP_VOIGT_WOFZ;
         if (!(k > 0 && in.same_lines_as_prev && !c->tune.no_shared_prep)) {       // (same line tables as the previous instrument: its records and
                                                        // generic-path flags are still in the workspace)
-            if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-            launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? c->d_genflag : (int*)nullptr, s);
+            if (gen && (rc_gf = genflag_acquire(c, W, s, &gf))) return rc_gf;
+            launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? gf.use : (int*)nullptr, s, gen ? gf.clear : (int*)nullptr);
         }
         const vp::InstDev& geom = sel ? in.dev_s : in.dev;
         // (the extra launch costs ~20 us; what it saves grows with walkers x blocks x lines -- measured on C2, us per pass
@@ -783,9 +802,9 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         }
         size_t m1 = prof ? prof_mark(c, s) : 0;
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin,
-                              gen ? c->d_genflag : (const int*)nullptr, &geom, 1, ff);
+                              gen ? gf.use : (const int*)nullptr, &geom, 1, ff);
         if (gen)
-            launch_tile<0, true>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin, c->d_genflag, &geom);
+            launch_tile<0, true>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin, gf.use, &geom);
         if (prof) {
             size_t m2 = prof_mark(c, s);
             c->spans.push_back({m0, m1, 0});
@@ -1780,10 +1799,11 @@ static int enqueue_model_flux(vp_ctx* c, int inst, int W, const double* d_theta,
     if ((rc = ensure_workspace(c, W))) return rc;
     const Instrument& in = c->inst[inst];
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;      // model_flux has no prior box: theta may be anything
-    if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-    launch_prep(c, in, d_theta, W, 0, nullptr, gen ? c->d_genflag : (int*)nullptr, s);
+    GenFlags gfl{nullptr, nullptr};
+    if (gen && (rc = genflag_acquire(c, W, s, &gfl))) return rc;
+    launch_prep(c, in, d_theta, W, 0, nullptr, gfl.use, s, gfl.clear);
     const vp::FinalizeArgs nofin{};
-    const int* gf = gen ? c->d_genflag : (const int*)nullptr;
+    const int* gf = gfl.use;
     // far lines from the blocks' expansions, as in the lnprob launches (convolved flux; same rule for when the extra launch pays)
     double* ff = nullptr;
     c->last_ff = vp_ctx::LastFF{};
@@ -1862,13 +1882,14 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;
-    if (gen) HIP_TRY(c, hipMemsetAsync(c->d_genflag, 0, (size_t)W * sizeof(int), s));
-    launch_prep(c, in, c->d_theta, W, 0, nullptr, gen ? c->d_genflag : (int*)nullptr, s);
+    GenFlags gfl{nullptr, nullptr};
+    if (gen && (rc = genflag_acquire(c, W, s, &gfl))) return rc;
+    launch_prep(c, in, c->d_theta, W, 0, nullptr, gfl.use, s, gfl.clear);
     const vp::FinalizeArgs nofin{};
     const size_t nrec = (size_t)(in.dev.L + in.dev.NCm) * vp::LC_STRIDE;
     for (int w0 = 0; w0 < W; w0 += wblock) {
         const int nw = std::min(wblock, W - w0);
-        const int* gf = gen ? c->d_genflag + w0 : (const int*)nullptr;
+        const int* gf = gen ? gfl.use + w0 : (const int*)nullptr;
         launch_tile<2, false>(in, c->d_lc + (size_t)w0 * nrec, nullptr, c->d_scratch, (int)(L * P), 0, nw, s, nofin, gf, nullptr, (int)L);
         if (gen) launch_tile<2, true>(in, c->d_lc + (size_t)w0 * nrec, nullptr, c->d_scratch, (int)(L * P), 0, nw, s, nofin, gf, nullptr, (int)L);
         HIP_TRY(c, hipGetLastError());

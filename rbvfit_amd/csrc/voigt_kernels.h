@@ -418,7 +418,8 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
                                                         const double* __restrict__ ub,
                                                         double* __restrict__ lc, int* __restrict__ flags,
                                                         int do_flags, double* __restrict__ lnprob_out,
-                                                        int* __restrict__ genflag, PrepGrid G, Replicas R) {
+                                                        int* __restrict__ genflag, PrepGrid G, Replicas R,
+                                                        int* __restrict__ genflag_clear = nullptr) {
     // direct-write gather (vp_gather_*): the batch before this one has arrived here from every rank before this one starts
     if (R.n > 1) replicas_handshake(R);
     const int nrec = T.L + T.NCm;                     // records per walker: lines, then clusters
@@ -434,6 +435,8 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         fill_record(rec, xok ? s.Tl : __builtin_nan(""), s.a);
         // lines outside the fast domain (a > 0.1, a < 0): their walker goes to the generic kernel
         if (genflag && (!(s.a >= 0.0) || s.a > 0.1) && (fabs(s.a) <= 1.79e308)) genflag[w] = 1;
+        // (the flags of the NEXT launch of this kind live in the other buffer: cleared here, so that no memset stands in front of it)
+        if (genflag_clear && l == 0) genflag_clear[w] = 0;
         rec[LC_A] = s.Ax;
         rec[LC_B] = s.Bx;
         rec[LC_D] = s.d;
