@@ -1592,6 +1592,9 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(Ins
     const int t = ot > 0 ? ot - 1 : (int)blockIdx.y, w = blockIdx.x;
     const int oob = (OUT == 0) ? flags[w] : 0;   // tested below, after the first loads are in flight
     const int gen = genflag ? genflag[w] : 0;
+    // (the generic instance's launch is almost always empty -- no walker left the fast domain --: its workgroups leave before
+    //  they ask for their pixels)
+    if (GENERIC && gen == 0) return;
     const int p0 = t * I.TP, nout = min(p0 + I.TP, I.P) - p0;
     const TilePre pre = tile_preload(I, p0, nout, threadIdx.x);
     if (oob) return;                    // out-of-bounds walker: likelihood is not evaluated
