@@ -181,6 +181,8 @@ struct vp_ctx {
                                  // record-preparation launch that fills one clears the other for the launch after it (genflag_acquire)
     unsigned gen_seq = 0;
     int gen_clean[2] = {0, 0};   // leading entries of each buffer known to be zero
+    int* h_gen_any = nullptr;    // mapped host memory, one word per buffer: did the launch that filled it flag ANY walker?  (what the
+    int* h_gen_any_dev = nullptr;   // generic launch of the NEXT batch is sized by: tile_generic_kernel's grid)
     double* d_ff = nullptr;      // (capW x cap_ffblk, FF_STRIDE) far-field expansions, instrument after instrument
     int cap_ffblk = 0;
     std::vector<double> h_lb;    // host copy of the lower bounds
@@ -385,7 +387,7 @@ int ensure_workspace(vp_ctx* c, int W) {
 template <int OUT, bool GENERIC>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
                  int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag, const vp::InstDev* geom = nullptr,
-                 int grid_z = 1, double* ff = nullptr) {
+                 int grid_z = 1, double* ff = nullptr, int gen_slots = 0) {
     const vp::InstDev& dev = geom ? *geom : in.dev;
     dim3 grid(W, dev.ntiles, grid_z);
     dim3 block(64 * in.nwaves);
@@ -409,8 +411,13 @@ void launch_tile(const Instrument& in, const double* lc, const int* flags, doubl
         if (!GENERIC)
             hipLaunchKernelGGL((vp::tile_kernel<1, OUT, false>), grid, block, in.lds_bytes, s, dev, lc, flags, out,
                                stride, offset, fin, genflag);
+    } else if (GENERIC) {
+        // (almost always an empty launch: a small grid whose workgroups walk the flagged walkers -- tile_generic_kernel)
+        //  where the batch before flagged none; one workgroup per walker otherwise, as a fit with damped lines needs them)
+        const dim3 gg(gen_slots > 0 ? std::min(W, gen_slots) : W, dev.ntiles, grid_z);
+        hipLaunchKernelGGL((vp::tile_generic_kernel<OUT>), gg, block, in.lds_bytes, s, dev, lc, flags, out, stride, offset, fin, genflag, W);
     } else {
-        hipLaunchKernelGGL((vp::tile_kernel<0, OUT, GENERIC>), grid, block, in.lds_bytes, s, dev, lc, flags, out,
+        hipLaunchKernelGGL((vp::tile_kernel<0, OUT, false>), grid, block, in.lds_bytes, s, dev, lc, flags, out,
                            stride, offset, fin, genflag);
     }
 }
@@ -446,19 +453,28 @@ size_t prof_mark(vp_ctx* c, hipStream_t s) {
 // faster even at 512 walkers x 4 lines; the prep_rpw knob overrides for experiments).
 // The generic-path flags of a record-preparation launch: the buffer whose turn it is, zero in its first W entries (a memset only
 // where the launch before could not vouch for that), and the other buffer, which this launch clears for the next one.
-struct GenFlags { int* use; int* clear; };
+struct GenFlags { int* use; int* clear; int* any; int* any_clear; int slots; };
 static int genflag_acquire(vp_ctx* c, int W, hipStream_t s, GenFlags* out) {
     const int b = (int)(c->gen_seq & 1u), o = b ^ 1;
+    if (!c->h_gen_any) {
+        if (hipHostMalloc((void**)&c->h_gen_any, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&c->h_gen_any_dev, c->h_gen_any, 0) == hipSuccess) {
+            c->h_gen_any[0] = c->h_gen_any[1] = 1;         // (nothing known yet: one workgroup per walker)
+        } else { c->h_gen_any = nullptr; c->h_gen_any_dev = nullptr; (void)hipGetLastError(); }
+    }
+    // the batch before this one flagged no walker: this one's generic launch will most likely be empty -- a small grid
+    const bool quiet = c->h_gen_any && __atomic_load_n(&c->h_gen_any[o], __ATOMIC_RELAXED) == 0;
     int* use = c->d_genflag + (size_t)b * c->capW;
     if (c->gen_clean[b] < W) HIP_TRY(c, hipMemsetAsync(use, 0, (size_t)W * sizeof(int), s));
     c->gen_clean[b] = 0;                                   // (written by this launch)
     if (c->gen_clean[o] < W) c->gen_clean[o] = W;          // (cleared by this launch)
     ++c->gen_seq;
-    *out = GenFlags{use, c->d_genflag + (size_t)o * c->capW};
+    *out = GenFlags{use, c->d_genflag + (size_t)o * c->capW, c->h_gen_any_dev ? c->h_gen_any_dev + b : nullptr,
+                    c->h_gen_any_dev ? c->h_gen_any_dev + o : nullptr, quiet ? vp::GEN_SLOTS : 0};
     return VP_OK;
 }
 static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_theta, int W, int do_flags, double* d_out,
-                        int* genflag, hipStream_t s, int* genflag_clear = nullptr) {
+                        int* genflag, hipStream_t s, int* genflag_clear = nullptr, int* gen_any = nullptr, int* gen_any_clear = nullptr) {
     const long nline = (long)W * in.dev.L, ncl = (long)W * in.dev.NCm;
     const int rpw = std::max(1, std::min(64, c->tune.prep_rpw));
     vp::PrepGrid g;
@@ -474,7 +490,7 @@ static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_t
     // (direct-write gather: the pass's first launch -- the one that applies the box prior -- handshakes with the peers)
     const vp::Replicas rep = (c->gather_rep && do_flags) ? *c->gather_rep : vp::Replicas{};
     hipLaunchKernelGGL(vp::prep_lines_kernel, dim3(g.nb_line + g.nb_cl + g.nb_flag), dim3(64), 0, s, d_theta, W, c->D,
-                       in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g, rep, genflag_clear);
+                       in.lines, c->d_lb, c->d_ub, c->d_lc, c->d_flags, do_flags, d_out, genflag, g, rep, genflag_clear, gen_any, gen_any_clear);
 }
 
 // walker_kernel: the whole batch in ONE launch (workgroup = walker, wave = tile).  Possible for a single
@@ -723,7 +739,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         }
     }
     bool ff_made = false;                            // this instrument's expansions came with the previous one's launch
-    GenFlags gf{c->d_genflag, nullptr};              // (the flags of the records in the workspace: shared by instruments that share those)
+    GenFlags gf{c->d_genflag, nullptr, nullptr, nullptr, 0};     // (the flags of the records in the workspace: shared by instruments that share those)
     int rc_gf = VP_OK;
     for (size_t k = 0; k < c->inst.size(); ++k) {
         const Instrument& in = c->inst[k];
@@ -731,7 +747,8 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         if (!(k > 0 && in.same_lines_as_prev && !c->tune.no_shared_prep)) {       // (same line tables as the previous instrument: its records and
                                                        // generic-path flags are still in the workspace)
             if (gen && (rc_gf = genflag_acquire(c, W, s, &gf))) return rc_gf;
-            launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? gf.use : (int*)nullptr, s, gen ? gf.clear : (int*)nullptr);
+            launch_prep(c, in, d_theta, W, k == 0 ? 1 : 0, d_out, gen ? gf.use : (int*)nullptr, s, gen ? gf.clear : (int*)nullptr,
+                        gen ? gf.any : (int*)nullptr, gen ? gf.any_clear : (int*)nullptr);
         }
         const vp::InstDev& geom = sel ? in.dev_s : in.dev;
         // (the extra launch costs ~20 us; what it saves grows with walkers x blocks x lines -- measured on C2, us per pass
@@ -804,7 +821,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         launch_tile<0, false>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin,
                               gen ? gf.use : (const int*)nullptr, &geom, 1, ff);
         if (gen)
-            launch_tile<0, true>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin, gf.use, &geom);
+            launch_tile<0, true>(in, c->d_lc, c->d_flags, c->d_partial, ntot, tile_off, W, s, fin, gf.use, &geom, 1, nullptr, gf.slots);
         if (prof) {
             size_t m2 = prof_mark(c, s);
             c->spans.push_back({m0, m1, 0});
@@ -1066,6 +1083,7 @@ int vp_ctx_destroy(vp_ctx* c) {
     hipDeviceSynchronize();
     if (c->arm.h) hipHostFree(c->arm.h);
     if (c->arm.slots) hipFree(c->arm.slots);
+    if (c->h_gen_any) hipHostFree(c->h_gen_any);
     for (auto& in : c->inst) for (void* p : in.allocs) hipFree(p);
     for (void* p : {(void*)c->d_lb, (void*)c->d_ub, (void*)c->d_theta, (void*)c->d_out, (void*)c->d_lc, (void*)c->d_partial,
                     (void*)c->d_flags, (void*)c->d_ticket, (void*)c->d_genflag, (void*)c->d_tile_off, (void*)c->d_sum_logw, (void*)c->d_scratch,
@@ -1799,9 +1817,9 @@ static int enqueue_model_flux(vp_ctx* c, int inst, int W, const double* d_theta,
     if ((rc = ensure_workspace(c, W))) return rc;
     const Instrument& in = c->inst[inst];
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;      // model_flux has no prior box: theta may be anything
-    GenFlags gfl{nullptr, nullptr};
+    GenFlags gfl{nullptr, nullptr, nullptr, nullptr, 0};
     if (gen && (rc = genflag_acquire(c, W, s, &gfl))) return rc;
-    launch_prep(c, in, d_theta, W, 0, nullptr, gfl.use, s, gfl.clear);
+    launch_prep(c, in, d_theta, W, 0, nullptr, gfl.use, s, gfl.clear, gfl.any, gfl.any_clear);
     const vp::FinalizeArgs nofin{};
     const int* gf = gfl.use;
     // far lines from the blocks' expansions, as in the lnprob launches (convolved flux; same rule for when the extra launch pays)
@@ -1822,10 +1840,10 @@ static int enqueue_model_flux(vp_ctx* c, int inst, int W, const double* d_theta,
     }
     if (convolved) {
         launch_tile<1, false>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf, nullptr, 1, ff);
-        if (gen) launch_tile<1, true>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
+        if (gen) launch_tile<1, true>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf, nullptr, 1, nullptr, gfl.slots);
     } else {
         launch_tile<2, false>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
-        if (gen) launch_tile<2, true>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf);
+        if (gen) launch_tile<2, true>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf, nullptr, 1, nullptr, gfl.slots);
     }
     HIP_TRY(c, hipGetLastError());
     return VP_OK;
@@ -1882,16 +1900,17 @@ int vp_model_flux_components(vp_ctx* c, int inst, int W, int D, const double* th
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->d_theta, theta, (size_t)W * D * sizeof(double), hipMemcpyHostToDevice, s));
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;
-    GenFlags gfl{nullptr, nullptr};
+    GenFlags gfl{nullptr, nullptr, nullptr, nullptr, 0};
     if (gen && (rc = genflag_acquire(c, W, s, &gfl))) return rc;
-    launch_prep(c, in, c->d_theta, W, 0, nullptr, gfl.use, s, gfl.clear);
+    launch_prep(c, in, c->d_theta, W, 0, nullptr, gfl.use, s, gfl.clear, gfl.any, gfl.any_clear);
     const vp::FinalizeArgs nofin{};
     const size_t nrec = (size_t)(in.dev.L + in.dev.NCm) * vp::LC_STRIDE;
     for (int w0 = 0; w0 < W; w0 += wblock) {
         const int nw = std::min(wblock, W - w0);
         const int* gf = gen ? gfl.use + w0 : (const int*)nullptr;
         launch_tile<2, false>(in, c->d_lc + (size_t)w0 * nrec, nullptr, c->d_scratch, (int)(L * P), 0, nw, s, nofin, gf, nullptr, (int)L);
-        if (gen) launch_tile<2, true>(in, c->d_lc + (size_t)w0 * nrec, nullptr, c->d_scratch, (int)(L * P), 0, nw, s, nofin, gf, nullptr, (int)L);
+        if (gen) launch_tile<2, true>(in, c->d_lc + (size_t)w0 * nrec, nullptr, c->d_scratch, (int)(L * P), 0, nw, s, nofin, gf, nullptr, (int)L,
+                                      nullptr, gfl.slots);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(out + (size_t)w0 * L * P, c->d_scratch, (size_t)nw * per_walker, hipMemcpyDeviceToHost, s));
     }

@@ -419,7 +419,8 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
                                                         double* __restrict__ lc, int* __restrict__ flags,
                                                         int do_flags, double* __restrict__ lnprob_out,
                                                         int* __restrict__ genflag, PrepGrid G, Replicas R,
-                                                        int* __restrict__ genflag_clear = nullptr) {
+                                                        int* __restrict__ genflag_clear = nullptr,
+                                                        int* __restrict__ gen_any = nullptr, int* __restrict__ gen_any_clear = nullptr) {
     // direct-write gather (vp_gather_*): the batch before this one has arrived here from every rank before this one starts
     if (R.n > 1) replicas_handshake(R);
     const int nrec = T.L + T.NCm;                     // records per walker: lines, then clusters
@@ -434,9 +435,13 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         const bool xok = (fabs(s.Ax) <= 1.79e308) && (fabs(s.Bx) <= 1.79e308);
         fill_record(rec, xok ? s.Tl : __builtin_nan(""), s.a);
         // lines outside the fast domain (a > 0.1, a < 0): their walker goes to the generic kernel
-        if (genflag && (!(s.a >= 0.0) || s.a > 0.1) && (fabs(s.a) <= 1.79e308)) genflag[w] = 1;
+        if (genflag && (!(s.a >= 0.0) || s.a > 0.1) && (fabs(s.a) <= 1.79e308)) {
+            genflag[w] = 1;
+            if (gen_any) *gen_any = 1;       // (mapped host memory: the host sizes the NEXT batch's generic launch by it)
+        }
         // (the flags of the NEXT launch of this kind live in the other buffer: cleared here, so that no memset stands in front of it)
         if (genflag_clear && l == 0) genflag_clear[w] = 0;
+        if (gen_any_clear && ridx == 0) *gen_any_clear = 0;
         rec[LC_A] = s.Ax;
         rec[LC_B] = s.Bx;
         rec[LC_D] = s.d;
@@ -1619,6 +1624,62 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(Ins
             for (int k = 1; k < nwaves; ++k) tile_sum += red[k];
             publish_partial(F, out, out_stride, w, out_offset + t, tile_sum);
         }
+    }
+}
+
+// The generic instance's launch (walkers with a line outside the fast domain, flagged by prep_lines_kernel; wofz only): in most
+// batches NO walker is flagged, and a grid of W x tiles workgroups that all leave at once still costs its dispatch (C1 4.8 us,
+// C2 11 us per pass).  Its grid is therefore GEN_SLOTS x tiles: a workgroup walks the walkers slot, slot + GEN_SLOTS, ... and
+// evaluates its tile for the flagged ones, exactly as tile_kernel<0, OUT, true> did for its one (walker, tile).
+constexpr int GEN_SLOTS = 64;
+template <int OUT>
+__global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_generic_kernel(InstDev I, const double* __restrict__ lc,
+                                                            const int* __restrict__ flags,
+                                                            double* __restrict__ out, int out_stride,
+                                                            int out_offset, FinalizeArgs F,
+                                                            const int* __restrict__ genflag, int W) {
+    extern __shared__ double fl[];
+    const int ot = I.core_hint[TILE_ORDER_AT + blockIdx.y];
+    const int t = ot > 0 ? ot - 1 : (int)blockIdx.y;
+    const int p0 = t * I.TP, nout = min(p0 + I.TP, I.P) - p0;
+    // the flags of this workgroup's walkers, 64 at a time across the lanes (every wave of the workgroup for itself): ONE memory
+    // round trip in the empty case instead of one per walker
+    const int lane_g = threadIdx.x & 63;
+    const int nmine = ((int)blockIdx.x < W) ? (W - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    for (int base = 0; base < nmine; base += 64) {
+      const int idx = base + lane_g;
+      const int fl_i = idx < nmine ? genflag[blockIdx.x + idx * gridDim.x] : 0;
+      unsigned long long todo = __ballot(fl_i != 0);
+      while (todo) {
+        const int bit = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const int w = blockIdx.x + (base + bit) * gridDim.x;
+        if (OUT == 0 && flags[w]) continue;          // out-of-bounds walker: likelihood is not evaluated
+        const TilePre pre = tile_preload(I, p0, nout, threadIdx.x);
+        rec_t lcw = as_rec(lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE);
+        if (OUT == 2 && I.line_sel == -2) {          // per-line profiles of ALL lines in one launch: grid.z = line, out (W, L, P)
+            InstDev J = I;
+            J.line_sel = blockIdx.z;
+            tile_work<0, OUT, true, false>(J, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x, pre, true,
+                                           out + (size_t)blockIdx.z * I.P, out_stride VP_STAMP_NONE);
+            __syncthreads();                         // (the LDS block is the next walker's)
+            continue;
+        }
+        const double wsum = wave_sum(tile_work<0, OUT, true, false, true, false, false>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x,
+                                                                                        pre, true, out, out_stride VP_STAMP_NONE, false, t));
+        if (OUT == 0) {
+            const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+            double* red = fl + I.span + FL_PAD;
+            if (lane == 0) red[wid] = wsum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tile_sum = red[0];
+                for (int k = 1; k < nwaves; ++k) tile_sum += red[k];
+                publish_partial(F, out, out_stride, w, out_offset + t, tile_sum);
+            }
+        }
+        __syncthreads();
+      }
     }
 }
 

@@ -190,8 +190,28 @@ def test_lines_outside_the_fast_domain(b_value):
                          g("zfac"), g("N_idx"), g("b_idx"), g("v_idx"), taps=g("taps"), lsf_mode=int(g("lsf_mode")))
         fl = e.model_flux(0, th)[0]
         lnp = e.lnprob(th)[0]
+        # The launch for the flagged walkers is sized by what the batch BEFORE flagged (none: a few workgroups that walk the
+        # walkers; some: one workgroup per walker): a mixed batch of 200 rows right after a quiet one, then again after itself,
+        # as lnprob (tile launches forced) and as model_flux -- same bits both times, and the oracle's values.
+        quiet = np.tile(z["theta_true"], (200, 1))
+        mixed = quiet.copy()
+        mixed[::7, 2] = b_value
+        mixed[::7, 0] = 12.0
+        e.set_option("walker", 0)
+        q0 = e.lnprob(quiet)
+        m1 = e.lnprob(mixed)               # after a quiet batch
+        m2 = e.lnprob(mixed)               # after a batch with flagged walkers
+        q1 = e.lnprob(quiet)
+        assert np.array_equal(m1, m2) and np.array_equal(q0, q1)
+        f0 = e.model_flux(0, quiet[:40])
+        f1 = e.model_flux(0, mixed[:40])
+        f2 = e.model_flux(0, mixed[:40])
+        assert np.array_equal(f1, f2) and np.array_equal(f0[1], f1[1])
     np.testing.assert_allclose(fl, ref_flux, rtol=0, atol=FLUX_ATOL)
     np.testing.assert_allclose(lnp, ref_lnp, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    np.testing.assert_allclose(m1[0], ref_lnp, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    np.testing.assert_allclose(m1[1], vo.lnprob(z["theta_true"], lb, ub, insts), rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    np.testing.assert_allclose(f1[0], ref_flux, rtol=0, atol=FLUX_ATOL)
 
 
 def test_vfit_mirror_and_compiled_model_on_device():
