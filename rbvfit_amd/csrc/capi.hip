@@ -90,6 +90,7 @@ struct Tuning {
                                 // caller's theta and the arithmetic.  -1: when the previous call came within prearm_us / 2 of the
                                 // one before returning (a sampler's loop), 0 never, 1 after every eligible call
     int prearm_us = 1000;       // how long a pre-armed launch waits for its batch before it leaves (the GPU is held meanwhile)
+    int flux_walker = 1;        // vp_model_flux_batch[_device]: batches the walker kernel would take as lnprob batches as ONE launch (0: prep + tile launches)
     int stretch_mailbox = 1;    // vp_stretch_run's overlapped half-steps (stretch_overlap) keep a walker's row, lnprob and version in one 64-byte
                                 // line per buffer where D <= 6 (StretchArgs::ovl = 2); 0 = separate arrays
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
@@ -107,7 +108,7 @@ const Knob g_knobs[] = {
     VP_KNOB(no_fused_accept, "RBVFIT_AMD_NO_FUSED_ACCEPT", 0), VP_KNOB(slice_rows, "RBVFIT_AMD_SLICE_ROWS", 0), VP_KNOB(walker_clusters, "RBVFIT_AMD_WALKER_CLUSTERS", 0), VP_KNOB(no_shared_prep, "RBVFIT_AMD_NO_SHARED_PREP", 0),
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
     VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
-    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(stretch_mailbox, "RBVFIT_AMD_STRETCH_MAILBOX", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0), VP_KNOB(walker_prio, "RBVFIT_AMD_WALKER_PRIO", 0), VP_KNOB(walker_perm_hex, "RBVFIT_AMD_WALKER_PERM_HEX", 1),
+    VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(stretch_mailbox, "RBVFIT_AMD_STRETCH_MAILBOX", 0), VP_KNOB(flux_walker, "RBVFIT_AMD_FLUX_WALKER", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0), VP_KNOB(walker_prio, "RBVFIT_AMD_WALKER_PRIO", 0), VP_KNOB(walker_perm_hex, "RBVFIT_AMD_WALKER_PERM_HEX", 1),
     VP_KNOB(prearm, "RBVFIT_AMD_PREARM", 0), VP_KNOB(prearm_us, "RBVFIT_AMD_PREARM_US", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
@@ -181,8 +182,8 @@ struct vp_ctx {
                                  // record-preparation launch that fills one clears the other for the launch after it (genflag_acquire)
     unsigned gen_seq = 0;
     int gen_clean[2] = {0, 0};   // leading entries of each buffer known to be zero
-    int* h_gen_any = nullptr;    // mapped host memory, one word per buffer: did the launch that filled it flag ANY walker?  (what the
-    int* h_gen_any_dev = nullptr;   // generic launch of the NEXT batch is sized by: tile_generic_kernel's grid)
+    int* h_gen_any = nullptr;    // mapped host memory, one word: has any launch of this context (with these bounds and instruments) flagged a
+    int* h_gen_any_dev = nullptr;   // walker?  (what the generic launches are sized by: tile_generic_kernel's grid)
     double* d_ff = nullptr;      // (capW x cap_ffblk, FF_STRIDE) far-field expansions, instrument after instrument
     int cap_ffblk = 0;
     std::vector<double> h_lb;    // host copy of the lower bounds
@@ -387,7 +388,7 @@ int ensure_workspace(vp_ctx* c, int W) {
 template <int OUT, bool GENERIC>
 void launch_tile(const Instrument& in, const double* lc, const int* flags, double* out, int stride, int offset,
                  int W, hipStream_t s, const vp::FinalizeArgs& fin, const int* genflag, const vp::InstDev* geom = nullptr,
-                 int grid_z = 1, double* ff = nullptr, int gen_slots = 0) {
+                 int grid_z = 1, double* ff = nullptr, int gen_slots = 0, const double* theta_rebuild = nullptr, int D = 0) {
     const vp::InstDev& dev = geom ? *geom : in.dev;
     dim3 grid(W, dev.ntiles, grid_z);
     dim3 block(64 * in.nwaves);
@@ -415,7 +416,12 @@ void launch_tile(const Instrument& in, const double* lc, const int* flags, doubl
         // (almost always an empty launch: a small grid whose workgroups walk the flagged walkers -- tile_generic_kernel)
         //  where the batch before flagged none; one workgroup per walker otherwise, as a fit with damped lines needs them)
         const dim3 gg(gen_slots > 0 ? std::min(W, gen_slots) : W, dev.ntiles, grid_z);
-        hipLaunchKernelGGL((vp::tile_generic_kernel<OUT>), gg, block, in.lds_bytes, s, dev, lc, flags, out, stride, offset, fin, genflag, W);
+        if (OUT == 1 && theta_rebuild)
+            hipLaunchKernelGGL((vp::tile_generic_kernel<1, true>), gg, block, in.lds_bytes, s, dev, lc, flags, out, stride, offset, fin, genflag, W,
+                               in.lines, theta_rebuild, D);
+        else
+            hipLaunchKernelGGL((vp::tile_generic_kernel<OUT, false>), gg, block, in.lds_bytes, s, dev, lc, flags, out, stride, offset, fin, genflag, W,
+                               in.lines, (const double*)nullptr, 0);
     } else {
         hipLaunchKernelGGL((vp::tile_kernel<0, OUT, false>), grid, block, in.lds_bytes, s, dev, lc, flags, out,
                            stride, offset, fin, genflag);
@@ -459,18 +465,19 @@ static int genflag_acquire(vp_ctx* c, int W, hipStream_t s, GenFlags* out) {
     if (!c->h_gen_any) {
         if (hipHostMalloc((void**)&c->h_gen_any, 64, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->h_gen_any_dev, c->h_gen_any, 0) == hipSuccess) {
-            c->h_gen_any[0] = c->h_gen_any[1] = 1;         // (nothing known yet: one workgroup per walker)
+            c->h_gen_any[0] = 0;
         } else { c->h_gen_any = nullptr; c->h_gen_any_dev = nullptr; (void)hipGetLastError(); }
     }
-    // the batch before this one flagged no walker: this one's generic launch will most likely be empty -- a small grid
-    const bool quiet = c->h_gen_any && __atomic_load_n(&c->h_gen_any[o], __ATOMIC_RELAXED) == 0;
+    // No batch of this context has flagged a walker so far (ONE word, set by the launches, never cleared by them: a fit with
+    // damped lines says so within its first batches and keeps one workgroup per walker from then on; batches enqueued ahead of
+    // the GPU would make anything finer unreliable): this batch's generic launch will most likely be empty -- a small grid
+    const bool quiet = c->h_gen_any && __atomic_load_n(&c->h_gen_any[0], __ATOMIC_RELAXED) == 0;
     int* use = c->d_genflag + (size_t)b * c->capW;
     if (c->gen_clean[b] < W) HIP_TRY(c, hipMemsetAsync(use, 0, (size_t)W * sizeof(int), s));
     c->gen_clean[b] = 0;                                   // (written by this launch)
     if (c->gen_clean[o] < W) c->gen_clean[o] = W;          // (cleared by this launch)
     ++c->gen_seq;
-    *out = GenFlags{use, c->d_genflag + (size_t)o * c->capW, c->h_gen_any_dev ? c->h_gen_any_dev + b : nullptr,
-                    c->h_gen_any_dev ? c->h_gen_any_dev + o : nullptr, quiet ? vp::GEN_SLOTS : 0};
+    *out = GenFlags{use, c->d_genflag + (size_t)o * c->capW, c->h_gen_any_dev, nullptr, quiet ? vp::GEN_SLOTS : 0};
     return VP_OK;
 }
 static void launch_prep(const vp_ctx* c, const Instrument& in, const double* d_theta, int W, int do_flags, double* d_out,
@@ -1104,6 +1111,7 @@ int vp_ctx_destroy(vp_ctx* c) {
 int vp_set_bounds(vp_ctx* c, int D, const double* lb, const double* ub) {
     if (!c) return VP_EINVAL;
     CtxGuard g(c);
+    if (c->h_gen_any) c->h_gen_any[0] = 0;          // (new prior box: nothing known about walkers outside the fast domain)
     if (D <= 0 || !lb || !ub) return fail(c, VP_EINVAL, "vp_set_bounds: D must be positive and lb/ub non-NULL");
     if (!c->inst.empty() && D != c->D) return fail(c, VP_ESTATE, "vp_set_bounds: D differs from the D the instruments were validated against");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1134,6 +1142,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
                       int* inst_index) {
     if (!c) return VP_EINVAL;
     CtxGuard g(c);
+    if (c->h_gen_any) c->h_gen_any[0] = 0;
     if (c->D <= 0) return fail(c, VP_ESTATE, "vp_add_instrument: call vp_set_bounds first (theta indices are validated against D)");
     if (P <= 0 || !wave || !flux || !inv_sigma2 || !log_inv_sigma2) return fail(c, VP_EINVAL, "vp_add_instrument: empty or NULL spectrum");
     if (L <= 0 || !lambda0 || !gamma || !f || !zfac || !N_idx || !b_idx || !v_idx) return fail(c, VP_EINVAL, "vp_add_instrument: empty or NULL line tables");
@@ -1819,7 +1828,6 @@ static int enqueue_model_flux(vp_ctx* c, int inst, int W, const double* d_theta,
     const bool gen = in.dev.method == VP_VOIGT_WOFZ;      // model_flux has no prior box: theta may be anything
     GenFlags gfl{nullptr, nullptr, nullptr, nullptr, 0};
     if (gen && (rc = genflag_acquire(c, W, s, &gfl))) return rc;
-    launch_prep(c, in, d_theta, W, 0, nullptr, gfl.use, s, gfl.clear, gfl.any, gfl.any_clear);
     const vp::FinalizeArgs nofin{};
     const int* gf = gfl.use;
     // far lines from the blocks' expansions, as in the lnprob launches (convolved flux; same rule for when the extra launch pays)
@@ -1829,6 +1837,25 @@ static int enqueue_model_flux(vp_ctx* c, int inst, int W, const double* d_theta,
         const double score = in.ff_cover * (double)W * in.dev.ntiles * in.dev.ff_nblk * in.ff_items;
         if (c->tune.flux_farfield > 0 || score >= (in.dev.ff_members ? 3.0e5 : 1.5e5)) ff = c->d_ff;
     }
+    // Batches the walker kernel takes as lnprob batches (one instrument, no cluster records, the workgroups fit the CUs): the rows in
+    // ONE launch, workgroup = walker -- records formed in the workgroup, no record-preparation launch in front (C1 at 512 rows
+    // 28 -> 24 us); walkers with a line outside the fast domain are left to the generic launch behind it, as in the tile path.
+    if (convolved && !ff && inst == 0 && c->inst.size() == 1 && in.dev.NCm == 0 && c->tune.flux_walker != 0 && !c->profiling &&
+        !c->gather_rep && walker_applies(c, W) && in.dev.method == VP_VOIGT_WOFZ) {
+        vp::WalkerArgs a{d_theta, c->d_lb, c->d_ub, c->d_lc, d_out, 0.0, c->D, (int)(walker_wave_lds(c) / sizeof(double)),
+                         walker_prio_for(c, W), walker_perm_for(c, W)};
+        a.flux_stride = in.dev.P;
+        a.genflag = gfl.use; a.genflag_clear = gfl.clear; a.gen_any = gfl.any; a.gen_any_clear = gfl.any_clear;
+        vp::InstDev d0 = in.dev_w;
+        vp::LinesDev t0 = in.lines;
+        d0.NCm = 0; t0.NCm = 0;
+        hipLaunchKernelGGL((vp::walker_kernel<0, false, false, false, 1>), dim3(W), dim3(64 * walker_tiles(c)), walker_lds_bytes(c), s, d0, t0, a,
+                           vp::StretchArgs{});
+        launch_tile<1, true>(in, c->d_lc, nullptr, d_out, in.dev.P, 0, W, s, nofin, gf, nullptr, 1, nullptr, gfl.slots, d_theta, c->D);
+        HIP_TRY(c, hipGetLastError());
+        return VP_OK;
+    }
+    launch_prep(c, in, d_theta, W, 0, nullptr, gfl.use, s, gfl.clear, gfl.any, gfl.any_clear);
     if (ff) {
         vp::InstDev g2 = in.dev;
         g2.ff = ff;

@@ -406,6 +406,24 @@ __device__ __forceinline__ void prep_cluster_lanes(const double* __restrict__ th
     }
 }
 
+// One line's whole record by one lane (every tier's constants: what prep_lines_kernel writes, and what a walker that leaves the
+// fast domain needs of the walker kernel's flux form)
+__device__ __forceinline__ LineScalars prep_line_record(const double* __restrict__ th, const LinesDev& T, int l, double* __restrict__ rec) {
+    const LineScalars s = line_scalars(th, T, l);
+    const bool xok = (fabs(s.Ax) <= 1.79e308) && (fabs(s.Bx) <= 1.79e308);
+    fill_record(rec, xok ? s.Tl : __builtin_nan(""), s.a);
+    rec[LC_A] = s.Ax;
+    rec[LC_B] = s.Bx;
+    rec[LC_D] = s.d;
+    rec[LC_RD] = 1.0 / s.d;               // must be the correctly rounded reciprocal (faithful_x)
+    rec[LC_CFD] = s.cfd;
+    rec[LC_FREQ0] = s.freq0;
+    rec[LC_IBF] = s.ibf;
+    reinterpret_cast<int*>(rec + LC_CL)[0] = T.NCm > 0 ? T.cl_mp[l] : -1;
+    reinterpret_cast<int*>(rec + LC_CL)[1] = T.NCm > 0 ? T.cl_end[l] : l + 1;
+    return s;
+}
+
 // Record preparation, one LANE per record.  Block roles by blockIdx.x:
 //   [0, nb_line)                 line records     index = blockIdx.x * rpw + lane  over (walker, line)
 //   [nb_line, nb_line + nb_cl)   cluster records  one lane per MEMBER, cl_wpw walkers per wave (T.M <= 64 members per walker:
@@ -431,9 +449,7 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         if (lane >= G.rpw || ridx >= W * T.L) return;
         const int w = ridx / T.L, l = ridx - w * T.L;
         double* rec = lc + ((size_t)w * nrec + l) * LC_STRIDE;
-        const LineScalars s = line_scalars(theta + (size_t)w * D, T, l);
-        const bool xok = (fabs(s.Ax) <= 1.79e308) && (fabs(s.Bx) <= 1.79e308);
-        fill_record(rec, xok ? s.Tl : __builtin_nan(""), s.a);
+        const LineScalars s = prep_line_record(theta + (size_t)w * D, T, l, rec);
         // lines outside the fast domain (a > 0.1, a < 0): their walker goes to the generic kernel
         if (genflag && (!(s.a >= 0.0) || s.a > 0.1) && (fabs(s.a) <= 1.79e308)) {
             genflag[w] = 1;
@@ -442,15 +458,6 @@ __global__ __launch_bounds__(64) void prep_lines_kernel(const double* __restrict
         // (the flags of the NEXT launch of this kind live in the other buffer: cleared here, so that no memset stands in front of it)
         if (genflag_clear && l == 0) genflag_clear[w] = 0;
         if (gen_any_clear && ridx == 0) *gen_any_clear = 0;
-        rec[LC_A] = s.Ax;
-        rec[LC_B] = s.Bx;
-        rec[LC_D] = s.d;
-        rec[LC_RD] = 1.0 / s.d;               // must be the correctly rounded reciprocal (faithful_x)
-        rec[LC_CFD] = s.cfd;
-        rec[LC_FREQ0] = s.freq0;
-        rec[LC_IBF] = s.ibf;
-        reinterpret_cast<int*>(rec + LC_CL)[0] = T.NCm > 0 ? T.cl_mp[l] : -1;
-        reinterpret_cast<int*>(rec + LC_CL)[1] = T.NCm > 0 ? T.cl_end[l] : l + 1;
         return;
     }
     blk -= G.nb_line;
@@ -1632,12 +1639,13 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(Ins
 // C2 11 us per pass).  Its grid is therefore GEN_SLOTS x tiles: a workgroup walks the walkers slot, slot + GEN_SLOTS, ... and
 // evaluates its tile for the flagged ones, exactly as tile_kernel<0, OUT, true> did for its one (walker, tile).
 constexpr int GEN_SLOTS = 64;
-template <int OUT>
+template <int OUT, bool REBUILD = false>      // REBUILD: behind walker_kernel's flux form (whole records are formed here first)
 __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_generic_kernel(InstDev I, const double* __restrict__ lc,
                                                             const int* __restrict__ flags,
                                                             double* __restrict__ out, int out_stride,
                                                             int out_offset, FinalizeArgs F,
-                                                            const int* __restrict__ genflag, int W) {
+                                                            const int* __restrict__ genflag, int W,
+                                                            LinesDev T, const double* __restrict__ theta_rebuild, int D) {
     extern __shared__ double fl[];
     const int ot = I.core_hint[TILE_ORDER_AT + blockIdx.y];
     const int t = ot > 0 ? ot - 1 : (int)blockIdx.y;
@@ -1655,6 +1663,15 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_generic_ke
         todo &= todo - 1ull;
         const int w = blockIdx.x + (base + bit) * gridDim.x;
         if (OUT == 0 && flags[w]) continue;          // out-of-bounds walker: likelihood is not evaluated
+        if (REBUILD) {
+            // the walker comes from walker_kernel's flux form, whose records hold the fast domain's constants only: whole records
+            // first (every workgroup of the walker's tiles writes the same bytes; each reads what it has written itself)
+            double* __restrict__ rows = const_cast<double*>(lc) + (size_t)w * (I.L + I.NCm) * LC_STRIDE;
+            for (int l = threadIdx.x; l < I.L; l += (int)blockDim.x)
+                (void)prep_line_record(theta_rebuild + (size_t)w * D, T, l, rows + (size_t)l * LC_STRIDE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         const TilePre pre = tile_preload(I, p0, nout, threadIdx.x);
         rec_t lcw = as_rec(lc + (size_t)w * (I.L + I.NCm) * LC_STRIDE);
         if (OUT == 2 && I.line_sel == -2) {          // per-line profiles of ALL lines in one launch: grid.z = line, out (W, L, P)
@@ -1867,6 +1884,15 @@ struct WalkerArgs {
     unsigned int arm_seq;
     int arm_ticks;
     int arm_slot_doubles;
+    // Flux form (walker_kernel<..., FLUX = 1>, vp_model_flux_batch*): `lnprob` is the (W, flux_stride) output, there is no prior box,
+    // and a walker with a line outside the fast domain is not evaluated here: its flag is set (genflag, gen_any -- what
+    // prep_lines_kernel does in the tile path) and tile_generic_kernel, launched behind, takes it from the records left in the
+    // workspace.  genflag_clear / gen_any_clear: the other flag buffer, cleared for the launch after this one.
+    int flux_stride;
+    int* genflag;
+    int* genflag_clear;
+    int* gen_any;
+    int* gen_any_clear;
 };
 
 constexpr int ARM_GO = 1, ARM_LEAVE = 2;
@@ -1952,7 +1978,8 @@ __device__ __forceinline__ void walker_result(const WalkerArgs& A, const Replica
 // tiles of instrument k, Ik its geometry and spectrum, tb.slw[k-1] its weight constant; the tile sums are added per
 // instrument, in order, as finalize_kernel does.
 struct WalkerMore { int t[3]; double slw[3]; };
-template <int METHOD, bool CLUSTERS, bool SAMPLER, int NI, bool ARMED = false>   // ARMED: pre-armed launch (WalkerArgs::arm_*; an instance of
+template <int METHOD, bool CLUSTERS, bool SAMPLER, int NI, bool ARMED = false, int FLUX = 0>   // FLUX: the convolved model flux instead of lnprob
+                                       // (WalkerArgs::flux_stride ...).  ARMED: pre-armed launch (WalkerArgs::arm_*; an instance of
                                        // its own, so that the ordinary launch's entry is compiled without the wait).  CLUSTERS: the instrument has multipole cluster records (their
                                        // preparation needs more registers than the tile work and spills to scratch;
                                        // kept out of the plain instance).  SAMPLER: stretch-move half-step (StretchArgs)
@@ -2078,9 +2105,17 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     auto run_tasks = [&](double th, bool rehearsal) {
         for (int task = wid; task < ntask; task += nw) {
             if (task == 0) {
+                if (FLUX) {                          // (no prior box; the other flag buffer is cleared for the launch after this one)
+                    if (lane == 0) {
+                        red[nw] = 0.0;
+                        if (A.genflag_clear) A.genflag_clear[w] = 0;
+                        if (A.gen_any_clear && w == 0) *A.gen_any_clear = 0;
+                    }
+                } else {
                 const bool oob = lane < A.D && ((th < A.lb[min(lane, A.D - 1)]) || (th > A.ub[min(lane, A.D - 1)]));
                 const bool any = __ballot(oob) != 0ull;
                 if (lane == 0) red[nw] = any ? 1.0 : 0.0;
+                }
             } else if (task <= ngrp) {
                 prep_record_lanes(th, T, (task - 1) * 4, lcw, lane);
             } else if (CLUSTERS && !rehearsal) {
@@ -2160,6 +2195,25 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         return;
     }
     double total = 0.0;
+    if (FLUX) {
+        // a line outside the fast domain (the records' mode words, a lane each, every wave for itself): the generic launch's walker
+        unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
+        asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
+        const double* __restrict__ recs = reinterpret_cast<const double*>(pq);
+        bool bad = false;
+        for (int l = lane; l < T.L; l += 64) bad = bad || reinterpret_cast<const int*>(recs + (size_t)l * LC_STRIDE + LC_MODE)[0] != 0;
+        if (__ballot(bad) != 0ull) {
+            // (the records formed above carry the fast domain's constants only: tile_generic_kernel forms whole ones for the
+            //  walkers it takes over -- that code would cost THIS kernel registers it has no use for otherwise)
+            if (tid == 0) {
+                if (A.genflag) A.genflag[w] = 1;
+                if (A.gen_any) *A.gen_any = 1;
+            }
+            return;
+        }
+        (void)tile_work<METHOD, FLUX, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, A.lnprob, A.flux_stride VP_STAMP_PASS, daw_ready);
+        return;
+    }
     if (!oobw) {
         // the record pointer is re-made behind the barrier through an opaque scalar move, so no record load
         // can be scheduled above it
@@ -2241,9 +2295,9 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     }
 }
 
-template <int METHOD, bool CLUSTERS, bool SAMPLER, bool ARMED = false>
+template <int METHOD, bool CLUSTERS, bool SAMPLER, bool ARMED = false, int FLUX = 0>
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A, StretchArgs S) {
-    walker_body<METHOD, CLUSTERS, SAMPLER, 1, ARMED>(I, I, I, I, WalkerMore{}, T, A, S);
+    walker_body<METHOD, CLUSTERS, SAMPLER, 1, ARMED, FLUX>(I, I, I, I, WalkerMore{}, T, A, S);
 }
 template <int METHOD, bool SAMPLER, bool ARMED = false>
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel2(InstDev I, InstDev I1, WalkerMore tb, LinesDev T, WalkerArgs A,

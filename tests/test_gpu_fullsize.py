@@ -207,6 +207,21 @@ def test_lines_outside_the_fast_domain(b_value):
         f1 = e.model_flux(0, mixed[:40])
         f2 = e.model_flux(0, mixed[:40])
         assert np.array_equal(f1, f2) and np.array_equal(f0[1], f1[1])
+    # ... and with the fixture's own prior box (every line of an in-bounds walker in the fast domain): model_flux has no box, its
+    # small batches are ONE walker_kernel launch (flux form) that leaves the rows with a line outside the fast domain to the
+    # generic launch behind it -- mixed rows, after a quiet batch and after a flagged one, and a batch of flagged rows only
+    with rbvfit_amd.Engine(0) as e2:
+        e2.set_bounds(z["lb"], z["ub"])
+        e2.add_instrument(g("wave"), g("flux"), g("inv_sigma2"), g("log_inv_sigma2"), g("lambda0"), g("gamma"), g("f"),
+                          g("zfac"), g("N_idx"), g("b_idx"), g("v_idx"), taps=g("taps"), lsf_mode=int(g("lsf_mode")))
+        w0 = e2.model_flux(0, quiet[:40])
+        w1 = e2.model_flux(0, mixed[:40])
+        w2 = e2.model_flux(0, mixed[:40])
+        w3 = e2.model_flux(0, np.tile(th, (5, 1)))
+        e2.set_option("flux_walker", 0)
+        t1 = e2.model_flux(0, mixed[:40])
+    assert np.array_equal(w1, w2) and np.array_equal(w1, t1) and np.array_equal(w0[1], w1[1]) and np.array_equal(w3[0], w1[0])
+    np.testing.assert_allclose(w1[0], ref_flux, rtol=0, atol=FLUX_ATOL)
     np.testing.assert_allclose(fl, ref_flux, rtol=0, atol=FLUX_ATOL)
     np.testing.assert_allclose(lnp, ref_lnp, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
     np.testing.assert_allclose(m1[0], ref_lnp, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
