@@ -284,8 +284,10 @@ def model_flux_main(args, wl, d_theta, stream, rank, world, use_dist, spread_not
     bytes_algo = bytes_written + W * sum(16 * P for P in wl.pixels) + 8 * D * W       # + wave and 1/wave... read once per walker-eval
     achieved = bytes_written / (step_ms * 1e-3) / 1e9
     roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
-                kernel="vp::tile_kernel<0, 1, false, %s> (+ prep_lines_kernel%s, the generic instance's empty launch)" % (
-                    "true" if ff_kind != "none" else "false", ", farfield_kernel" if ff_kind != "none" else ""),
+                kernel=("vp::walker_kernel<0, false, false, false, 1> (the rows in ONE launch; + tile_generic_kernel's small grid behind it)"
+                        if (ff_kind == "none" and W * max(1, len(wl.pixels)) <= 512 and len(wl.pixels) == 1) else
+                        "vp::tile_kernel<0, 1, false, %s> (+ prep_lines_kernel%s, tile_generic_kernel's small grid)" % (
+                            "true" if ff_kind != "none" else "false", ", farfield_kernel" if ff_kind != "none" else "")),
                 avg_kernel_ms=step_ms, kernel_timing="HIP events on the launch stream around 100 back-to-back steps: the WHOLE step "
                 "(all its launches), not the tile kernel alone -- profiles/ has the rocprofv3 per-kernel means",
                 algorithmic_bytes_per_launch=bytes_written, bytes_written_per_step=bytes_written,

@@ -224,7 +224,7 @@ int vp_profile_read(vp_ctx* ctx, double* prep_ms, double* tile_ms, double* final
  * the per-call path.  Names: "geom" (-1 by batch size, 0 two-pass tiles, 1 one-pass tiles), "finalize"
  * (-1 auto, 0 own launch, 1 ticket), "walker" (-1 by batch size, 0 never, 1 whenever possible: the whole
  * batch as ONE launch, workgroup = walker), "prep_rpw", "zerocopy_max", "no_zerocopy", "no_fused_accept",
- * "slice_rows", "slice_seg", "tile_lpt", "walker_clusters", "prearm", "prearm_us" (vp_lnprob_batch); "span", "waves", "no_multipole", "multipole_min", "lds_pad" and "farfield" (-1: per-block far-field
+ * "slice_rows", "slice_seg", "tile_lpt", "walker_clusters", "prearm", "prearm_us" (vp_lnprob_batch), "flux_walker" (vp_model_flux_batch*: 1 / 0); "span", "waves", "no_multipole", "multipole_min", "lds_pad" and "farfield" (-1: per-block far-field
  * expansions for instruments with >= 8 lines in batches large enough to pay for the extra launch, 0 never, 1 whenever possible) apply to instruments added afterwards ("farfield" also at run time: 0 leaves the tables of an instrument unused, 1 uses them for every batch).
  * Unknown name -> VP_EINVAL.  (RBVFIT_AMD_VERBOSE in the environment makes vp_add_instrument print its far-field coverage
  * estimate to stderr; RBVFIT_AMD_LIB selects another build of the library in the Python loader.) */
