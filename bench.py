@@ -166,6 +166,13 @@ def _describe(wl):
             for d, sp in zip(wl.tables, wl.spectra)]
 
 
+def host_cores():
+    """Cores the CPU-baseline legs use: every core this process may run on (its affinity mask = the box's CPU share), or
+    BENCH_CPU_CORES; at most 128 workers (the GPU boxes limit the number of processes a job may hold)."""
+    n = int(os.environ.get("BENCH_CPU_CORES", "0")) or len(os.sched_getaffinity(0))
+    return max(1, min(128, n))
+
+
 def cpu_pool_baseline(pool, cores, wl, budget_s=5.0):
     descr, rows = _describe(wl), wl.thetas
     chunk = max(1, len(rows) // (4 * cores))         # Pool.map's default chunking
@@ -176,7 +183,7 @@ def cpu_pool_baseline(pool, cores, wl, budget_s=5.0):
         out = pool.map(_pool_chunk, tasks, chunksize=1)
         n += sum(len(o) for o in out)
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, cores=cores, kind="port",
+    return dict(value=n / dt, cores=cores, cores_reported=os.cpu_count(), kind="port",
                 sample=f"{n} lnprob calls through multiprocessing fork Pool({cores}).map over the {wl.name} "
                        f"walker rows ({dt:.1f} s, numpy/scipy oracle)")
 
@@ -202,8 +209,10 @@ def cpu_baseline(wl, budget_s=12.0):
     try:
         from oracle import c_oracle
         co = c_oracle.COracle(insts, wl.lb, wl.ub)
-        cores = min(16, len(os.sched_getaffinity(0)))     # the GPU box's CPU share per GPU
+        cores = host_cores()                              # every core the box gives this process
         sub = wl.thetas[:max(cores, min(len(wl.thetas), 64))]
+        if len(sub) < 2 * cores:                          # enough rows for every thread to have work
+            sub = np.concatenate([wl.thetas] * (2 * cores // max(1, len(wl.thetas)) + 1))[:2 * cores]
         co.lnprob_batch(sub[:cores], nthreads=cores)
         t0 = time.perf_counter()
         reps = 0
@@ -212,7 +221,7 @@ def cpu_baseline(wl, budget_s=12.0):
             reps += 1
         dtc = time.perf_counter() - t0
         m = min(len(cvals), len(vals))
-        base["c_openmp"] = dict(value=reps * len(sub) / dtc, cores=cores, kind="port",
+        base["c_openmp"] = dict(value=reps * len(sub) / dtc, cores=cores, cores_reported=os.cpu_count(), kind="port",
                                 sample=f"{reps} x {len(sub)} walkers, oracle/voigt_oracle.c, OpenMP",
                                 max_rel_vs_numpy_oracle=float(np.max(np.abs(cvals[:m] / np.array(vals[:m]) - 1))))
     except Exception as e:                                   # the C oracle is optional for the baseline
@@ -356,7 +365,7 @@ def rank_main(args):
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline
             and not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)):
         import multiprocessing as mp
-        pool_cores = min(16, len(os.sched_getaffinity(0)))
+        pool_cores = host_cores()                      # all host cores the box reports for this process
         pool = mp.get_context("fork").Pool(pool_cores)
 
     # the library (and the oracle's C restatement) is built -- compilers are child processes -- BEFORE this process touches

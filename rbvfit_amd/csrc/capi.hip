@@ -118,7 +118,8 @@ void set_knob(Tuning& t, const Knob& k, long v) {
 Tuning tuning_from_env() {
     Tuning t;
     for (const Knob& k : g_knobs)
-        if (const char* e = getenv(k.env)) set_knob(t, k, *e ? (long)strtoull(e, nullptr, 0) : 1);     // set but empty counts as 1 (decimal, 0x.., negative)
+        if (const char* e = getenv(k.env))      // set but empty counts as 1; decimal ("010" is ten), hexadecimal for the explicit tile deal alone
+            set_knob(t, k, *e ? (std::strcmp(k.name, "walker_perm_hex") == 0 ? (long)strtoull(e, nullptr, 16) : strtol(e, nullptr, 10)) : 1);
     return t;
 }
 
@@ -156,6 +157,7 @@ struct Instrument {
 
 struct vp_ctx {
     int device = 0;
+    pid_t pid = 0;               // the process that created the context (a forked child must not touch its mappings: prearm_leave_all_at_exit)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // vp_stretch_run's overlapped half-steps: the odd half-steps (made on first use)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -215,6 +217,9 @@ struct vp_ctx {
         int slot_doubles = 0, slot_rows = 0;
         const double* theta_src = nullptr;    // the caller's theta of the batch in flight (only the slots have it so far)
         bool live = false;            // a launch is waiting on the stream (or has expired there)
+        bool dirty = false;           // a pre-armed launch has been put on live_stream since the last fence: it writes rehearsal records into the
+                                      // shared workspace even when it is sent away, so work on ANOTHER stream must be ordered behind it (foreign_stream_fence)
+        hipEvent_t ev = nullptr;
         uint32_t seq = 0;             // ... with this sequence number
         int W = 0;                    // ... for this many rows
         hipStream_t cur = nullptr;    // the stream of the launch that serves the current call
@@ -632,7 +637,8 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         a.arm_slot_doubles = c->arm.slot_doubles;
         a.arm_host = c->arm.h_dev;
         a.arm_seq = c->arm.seq;
-        a.arm_ticks = 100 * std::max(1, c->tune.prearm_us);
+        a.arm_ticks = 100 * std::min(std::max(1, c->tune.prearm_us), 100000);      // (100 MHz clock; at most 100 ms: far below the
+                                                                                   //  other waves' own bound of ~1 s of polling, SYNC_SPIN_LIMIT)
     }
     vp::StretchArgs st{};
     if (gather) st.rep = *gather;            // (the plain form's only use of the sampler arguments: where the results go)
@@ -873,14 +879,17 @@ void prearm_push(vp_ctx* c, int W, const double* theta, int code) {
         for (int w = 0; w < W; ++w) reinterpret_cast<volatile uint64_t*>(s + (size_t)w * n)[n - 1] = word;
     } else if (n == 8) {
         // one 64-byte line per row: the row, padding, the word -- written in address order, so the write-combining buffer goes out
-        // as one burst (should it be cut in two, the earlier bytes still arrive first)
+        // as one burst
+        // (no fence between row and word -- it would cut the burst in two --: the word carries a fold of the row's bits in its upper
+        //  half and the waiting workgroup takes the row only when it matches, arm_wait)
         for (int w = 0; w < W; ++w) {
             volatile double* q = s + (size_t)w * 8;
             const double* t = theta + (size_t)w * D;
+            uint64_t h = 0;
             int k = 0;
-            for (; k < D; ++k) q[k] = t[k];
+            for (; k < D; ++k) { uint64_t b; std::memcpy(&b, t + k, 8); h ^= b; q[k] = t[k]; }
             for (; k < 7; ++k) q[k] = 0.0;
-            reinterpret_cast<volatile uint64_t*>(q)[7] = word;
+            reinterpret_cast<volatile uint64_t*>(q)[7] = word | ((uint64_t)(uint32_t)(h ^ (h >> 32)) << 32);
         }
     } else {
         for (int w = 0; w < W; ++w) std::memcpy(s + (size_t)w * n, theta + (size_t)w * D, (size_t)D * sizeof(double));
@@ -945,8 +954,19 @@ int prearm_launch(vp_ctx* c, int W) {
     launch_walker(c, W, dp, dp + (size_t)W * c->D, s, nullptr, true);
     HIP_TRY(c, hipGetLastError());
     c->arm.live = true;
+    c->arm.dirty = true;
     c->arm.live_stream = s;
     c->arm.W = W;
+    return VP_OK;
+}
+// An entry point about to enqueue on a stream of the caller's: a pre-armed launch -- waiting, sent away or expired -- may still be
+// writing its rehearsal records into the context's record workspace on the context's own stream; order the caller's stream behind it.
+int foreign_stream_fence(vp_ctx* c, hipStream_t s) {
+    if (!c->arm.dirty || !c->arm.live_stream || s == c->arm.live_stream) return VP_OK;       // (same stream: stream order does it)
+    if (!c->arm.ev) HIP_TRY(c, hipEventCreateWithFlags(&c->arm.ev, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->arm.ev, c->arm.live_stream));
+    HIP_TRY(c, hipStreamWaitEvent(s, c->arm.ev, 0));
+    c->arm.dirty = false;
     return VP_OK;
 }
 // Contexts alive in this process: a program that ends without vp_ctx_destroy must not leave a launch waiting on the GPU while the
@@ -956,8 +976,11 @@ std::vector<vp_ctx*> g_ctxs;
 void prearm_leave_all_at_exit() {
     std::lock_guard<std::mutex> g(g_ctx_mu);
     bool any = false;
+    const pid_t me = getpid();
     for (vp_ctx* c : g_ctxs)
-        if (c->mu.try_lock()) {
+        // (a forked child that leaves through exit() runs this handler too: the parent's device mappings are not in its address
+        //  space -- ROCm marks them MADV_DONTFORK -- and the launch is the parent's to send away)
+        if (c->pid == me && c->mu.try_lock()) {
             any |= c->arm.live;
             prearm_cancel(c);
             c->mu.unlock();
@@ -968,6 +991,7 @@ void ctx_register(vp_ctx* c) {
     std::lock_guard<std::mutex> g(g_ctx_mu);
     static bool hooked = false;
     if (!hooked) { std::atexit(prearm_leave_all_at_exit); hooked = true; }     // (behind the HIP runtime's own handlers: runs before them)
+    c->pid = getpid();
     g_ctxs.push_back(c);
 }
 void ctx_unregister(vp_ctx* c) {
@@ -1089,6 +1113,7 @@ int vp_ctx_destroy(vp_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     if (c->arm.h) hipHostFree(c->arm.h);
+    if (c->arm.ev) hipEventDestroy(c->arm.ev);
     if (c->arm.slots) hipFree(c->arm.slots);
     if (c->h_gen_any) hipHostFree(c->h_gen_any);
     for (auto& in : c->inst) for (void* p : in.allocs) hipFree(p);
@@ -1447,6 +1472,7 @@ int vp_lnprob_batch_device(vp_ctx* c, int W, int D, const double* d_theta, doubl
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if ((rc = foreign_stream_fence(c, s))) return rc;
     return enqueue_lnprob(c, W, d_theta, d_out, s);
 }
 
@@ -1571,6 +1597,7 @@ int vp_lnprob_gather_device(vp_ctx* c, int W, int D, const double* d_theta, void
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_workspace(c, W))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if ((rc = foreign_stream_fence(c, s))) return rc;
     vp::Replicas R = gather_replicas(c, ++G.seq);
     if (G.shared_device && G.world > 1) {            // the handshake as a one-wave launch in front of the pass
         hipLaunchKernelGGL(gather_wait_kernel, dim3(1), dim3(64), 0, s, R);
@@ -1741,7 +1768,8 @@ static int host_wait(vp_ctx* c) {
             if (i == W) { VP_HSTAMP(3); if (c->arm.inflight) c->arm.misses = 0; return VP_OK; }
             __builtin_ia32_pause();
             if (c->arm.inflight && (spins & 63u) == 63u &&
-                __atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) == c->arm.seq_inflight) {
+                (__atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) == c->arm.seq_inflight ||
+                 __atomic_load_n(&c->arm.h[vp::ARM_STUCK_WORD], __ATOMIC_ACQUIRE) == c->arm.seq_inflight)) {      // (a workgroup gave up on its own: same cure)
                 ++c->arm.expired; --c->arm.used;
                 // (the go words were on their way and the launch still gave up: once is a caller that arrived at the last moment;
                 //  three times in a row is a system where the pushes do not reach the launch in time -- no more pre-armed launches)
@@ -1885,7 +1913,9 @@ int vp_model_flux_batch_device(vp_ctx* c, int inst, int W, int D, const double* 
     if (inst < 0 || inst >= (int)c->inst.size()) return fail(c, VP_EINVAL, "vp_model_flux_batch: instrument index out of range");
     if (W == 0) return VP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    return enqueue_model_flux(c, inst, W, d_theta, d_out, convolved, hip_stream ? (hipStream_t)hip_stream : c->stream);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if ((rc = foreign_stream_fence(c, s))) return rc;
+    return enqueue_model_flux(c, inst, W, d_theta, d_out, convolved, s);
 }
 
 int vp_model_flux_batch(vp_ctx* c, int inst, int W, int D, const double* theta, double* out, int convolved) {

@@ -1915,8 +1915,20 @@ __device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int
             flag = __builtin_amdgcn_readfirstlane((unsigned int)flag) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(flag >> 32)) << 32);
             row = 0ull;
         }
-        if ((unsigned int)(flag >> 2) == A.arm_seq) {
-            const int code = (int)(flag & 3ull);
+        bool mine = ((unsigned int)flag >> 2) == A.arm_seq;
+        const int code = (int)(flag & 3ull);
+        if (mine && code == ARM_GO && n == 8) {
+            // one line, written by the host as ONE write-combined burst with no fence between row and word: should the burst be
+            // cut (an interrupt, buffer pressure) x86 does not promise that its 8-byte pieces land in address order, so the word
+            // vouches for the row itself -- its upper half is a fold of the row's bits (prearm_push); a line whose row does
+            // not match yet is polled again (behind the keeper's look at the clock: a wait stays bounded whatever the slot holds)
+            unsigned long long h = 0ull;
+            for (int k = 0; k < A.D; ++k)
+                h ^= (unsigned long long)__builtin_amdgcn_readlane((unsigned int)row, k) |
+                     ((unsigned long long)__builtin_amdgcn_readlane((unsigned int)(row >> 32), k) << 32);
+            mine = (unsigned int)(h ^ (h >> 32)) == (unsigned int)(flag >> 32);
+        }
+        if (mine) {
             if (code == ARM_GO) {
                 // (several lines: the word was written behind a store fence, the row is read again now that it has been seen)
                 if (n != 8) row = __hip_atomic_load(slot + dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2153,7 +2165,10 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
                 }
                 run_tasks(thv, pass == 0);
             }
-            if (arm_code != ARM_GO && tid == 0) red[nw] = 2.0;      // (told to leave: nobody evaluates or writes anything)
+            // every record wave polls the slot on its own, and the slot's word can change between two polls (the keeper's
+            // "leave" against the host's "go" at the moment of expiry): each wave leaves ITS decision in a word of its own and
+            // the workgroup goes on only if all of them saw "go" -- decided once, behind the barrier, by everybody alike
+            if (lane == 0) stash[wid] = arm_code == ARM_GO ? 1.0 : 2.0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         VP_STAMP(10);
@@ -2176,7 +2191,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     __syncthreads();
     VP_STAMP(1);
 #ifdef VP_STAMPS
-    if (red[nw] != 2.0 && lane == 0 && w < STAMP_W) {
+    if ((!ARMED || arm_code == ARM_GO) && lane == 0 && w < STAMP_W) {
         long long* gs = g_stamps + (w * STAMP_WAVES + wid) * STAMP_STAGES;
         gs[14] = rt_entry; gs[12] = rt_go; gs[13] = wall_clock64();
     }
@@ -2188,8 +2203,12 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     //  24.4 us without, 21.5 with; a workgroup that has its CU to itself measured 1 % slower with it: 256 walkers 15.68 / 15.50)
     if (daw_ready && A.prio) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
 #endif
+    if (ARMED) {                                   // (told to leave, by the host or by the clock: nobody evaluates or writes anything)
+        bool leave = false;
+        for (int k = 0; k < min(ntask, nw); ++k) leave = leave || stash[k] != 1.0;
+        if (leave) return;
+    }
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
-    if (ARMED && red[nw] == 2.0) return;
     if (oobw && !SAMPLER) {
         if (tid == 0) walker_result(A, S.rep, w, -__builtin_inf());
         return;

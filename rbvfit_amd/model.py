@@ -136,28 +136,50 @@ def mean_fwhm_pixels(FWHM_vel_kms: float, wave_obs_grid) -> float:
     return float(np.mean(fwhm_lambda / delta_lambda))
 
 
+_ASTROPY_NORMALIZES = "unknown"
+
+
+def astropy_normalizes_gaussian() -> Optional[bool]:
+    """Does the installed astropy hand out sum-normalised ``Gaussian1DKernel`` arrays?  True / False from the package
+    itself (the kernel the reference would build, core/voigt_model.py:464: an 8-sigma truncation loses 6e-5 of the sum
+    unless the constructor renormalises), None where astropy cannot be imported.  Asked once per process."""
+    global _ASTROPY_NORMALIZES
+    if _ASTROPY_NORMALIZES == "unknown":
+        try:
+            from astropy.convolution import Gaussian1DKernel
+            _ASTROPY_NORMALIZES = bool(abs(float(np.sum(Gaussian1DKernel(2.0).array)) - 1.0) < 1e-9)
+        except Exception:
+            _ASTROPY_NORMALIZES = None
+    return _ASTROPY_NORMALIZES
+
+
 class VoigtModel:
     """Single-instrument model description.  ``FWHM`` is in pixels, as a string or float, or None
     for no LSF; ``kernel_taps`` supplies a tabulated LSF (the reference's 'COS' / CustomKernel
     branch -> normalising 'extend' convolution; ``FWHM='COS'`` itself needs linetools' tables, which
     this package does not carry: pass their samples as ``kernel_taps``).
 
-    ``normalize_kernel``: whether the Gaussian taps are divided by their sum.  The default, False, is
-    what ``Gaussian1DKernel(...).array`` holds under astropy 4.3.1 -- the only astropy the reference
-    could be run with here, and the version every golden fixture and SURVEY anchor was made with, so the
-    default path of this class is the pinned one (``tests/golden/taps.npz``).  True gives the same samples
-    divided by their sum (pinned against the same fixture, ``tests/test_host_logic.py``) for an astropy
-    whose Gaussian kernels are sum-normalised; for FWHM '6.5' the two differ by sum(taps) = 1 - 2.8e-5
-    on every pixel (trap T2).  The engine takes taps as data either way."""
+    ``normalize_kernel``: whether the Gaussian taps are divided by their sum (trap T2: for FWHM '6.5' the two
+    differ by sum(taps) = 1 - 2.8e-5 on every pixel).  False is what ``Gaussian1DKernel(...).array`` holds under
+    astropy 4.3.1 -- the only astropy the reference could be run with here, the version every golden fixture and
+    SURVEY anchor was made with (``tests/golden/taps.npz``); True gives the same samples divided by their sum
+    (pinned against the same fixture, ``tests/test_host_logic.py``).  The default, None, asks the astropy that is
+    installed next to this package -- the one the reference itself would build its kernel with -- whether its
+    ``Gaussian1DKernel`` is sum-normalised (``astropy_normalizes_gaussian``) and follows it; where no astropy is
+    importable it is False, the pinned behaviour.  ``VoigtModel.normalize_kernel`` records what was used.  The
+    engine takes taps as data either way."""
 
     def __init__(self, config: FitConfiguration, FWHM: Union[str, float, None] = "6.5",
                  voigt_method: str = "wofz", kernel_taps: Optional[Sequence[float]] = None,
-                 normalize_kernel: bool = False):
+                 normalize_kernel: Optional[bool] = None):
         if voigt_method not in ("wofz", "fast"):
             raise ValueError(f"voigt_method must be one of ('wofz', 'fast'), got '{voigt_method}'")
         self.voigt_method = voigt_method
         self.config = config
         self.config.validate()
+        if normalize_kernel is None:
+            normalize_kernel = bool(astropy_normalizes_gaussian())        # (None -- no astropy here -- counts as False)
+        self.normalize_kernel = bool(normalize_kernel)
         self.FWHM = config.instrumental_params.get("FWHM", FWHM)
         if kernel_taps is not None:
             self.taps, self.lsf_mode = np.asarray(kernel_taps, dtype=np.float64), L.LSF_ASTROPY_EXTEND

@@ -45,7 +45,33 @@ def _tables_of(model) -> CompiledModelData:
     if hasattr(model, "data") or hasattr(model, "atomic_lambda0"):  # reference CompiledVoigtModel / data
         return tables_from_rbvfit(model)
     raise TypeError("instrument 'model' must be a VoigtModel / CompiledVoigtModel / CompiledModelData "
-                    "(rbvfit_amd or rbvfit); arbitrary Python callables cannot run on the GPU")
+                    "(rbvfit_amd or rbvfit) or a callable model(theta, wave) -> flux")
+
+
+def _is_host_callable(model) -> bool:
+    """The reference's pass-through branch (vfit_mcmc.py:242-248): anything without ``.config`` / ``.compile`` is
+    stored as the model function itself and called as ``model(theta, wave)`` (:304).  Here: a plain callable that
+    carries no tables the GPU path could take (functions, lambdas, bound methods, functools.partial, objects with
+    ``__call__``) -- evaluated on the host, row by row, exactly like that."""
+    if isinstance(model, (CompiledModelData, CompiledVoigtModel, VoigtModel)):
+        return False
+    if hasattr(model, "config") and hasattr(model, "compile"):
+        return False
+    if hasattr(model, "data") or hasattr(model, "atomic_lambda0"):
+        return False
+    owner = getattr(model, "__self__", None)               # a bound model_flux of a compiled model: take its tables
+    if owner is not None and (isinstance(owner, CompiledVoigtModel) or hasattr(owner, "data") or hasattr(owner, "atomic_lambda0")):
+        return False
+    return callable(model)
+
+
+def _unwrap_bound(model):
+    """``compiled.model_flux`` (what the reference's ``_compile_models`` itself stores) -> the compiled model."""
+    owner = getattr(model, "__self__", None)
+    if owner is not None and not isinstance(model, (CompiledModelData, CompiledVoigtModel, VoigtModel)) and \
+            (isinstance(owner, CompiledVoigtModel) or hasattr(owner, "data") or hasattr(owner, "atomic_lambda0")):
+        return owner
+    return model
 
 
 class vfit:
@@ -68,22 +94,33 @@ class vfit:
         self.engine = Engine(device_id)
         self.engine.set_bounds(self.lb, self.ub)
         self.instrument_data = {}
+        self._host_instruments = []        # entries whose model is a user callable (vfit_mcmc.py:242-248): evaluated on the host
+        self._n_gpu = 0
         for name, data in instrument_data.items():
-            tables = _tables_of(data["model"])
-            if 3 * tables.total_components != self.ndim:
-                raise ValueError(f"instrument '{name}': model has {3 * tables.total_components} parameters, "
-                                 f"theta has {self.ndim}")
             error = np.asarray(data["error"])
             entry = {
-                "tables": tables,
                 "wave": np.asarray(data["wave"]),
                 "flux": np.asarray(data["flux"]),
                 "error": error,
                 "inv_sigma2": 1.0 / (error ** 2),                  # vfit_mcmc.py:255 (dtype of error, T4)
                 "log_inv_sigma2": np.log(1.0 / (error ** 2)),      # :256
             }
-            entry["index"] = self.engine.add_instrument(entry["wave"], entry["flux"], entry["inv_sigma2"],
-                                                        entry["log_inv_sigma2"], **tables.engine_kwargs())
+            model = _unwrap_bound(data["model"])
+            if _is_host_callable(model):
+                # the reference takes ANY callable (theta(D,), wave(P,)) -> flux(P,) verbatim; it cannot run on the GPU, so
+                # its likelihood term is formed on the host per row and added to the GPU instruments' (lnprob below)
+                entry["model"] = model
+                entry["index"] = None
+                self._host_instruments.append(entry)
+            else:
+                tables = _tables_of(model)
+                if 3 * tables.total_components != self.ndim:
+                    raise ValueError(f"instrument '{name}': model has {3 * tables.total_components} parameters, "
+                                     f"theta has {self.ndim}")
+                entry["tables"] = tables
+                entry["index"] = self.engine.add_instrument(entry["wave"], entry["flux"], entry["inv_sigma2"],
+                                                            entry["log_inv_sigma2"], **tables.engine_kwargs())
+                self._n_gpu += 1
             self.instrument_data[name] = entry
 
     # -- validation (vfit_mcmc.py:199-229) -----------------------------------------------------
@@ -120,10 +157,39 @@ class vfit:
         out = np.where(oob, -np.inf, 0.0)
         return float(out) if th.ndim == 1 else out
 
+    def _host_lnlike_rows(self, rows):
+        """Sum over the user-callable instruments of -0.5 sum((flux - model(theta, wave))**2 w - log w) for each row
+        (vfit_mcmc.py:302-313, the callable invoked as ``data['model'](theta, data['wave'])``, :304).  ANY exception
+        while a row is evaluated makes that row's likelihood -inf, as the reference's ``except Exception`` does
+        (:317-319); NaN is not caught and propagates."""
+        out = np.zeros(len(rows), dtype=np.float64)
+        for i, th in enumerate(rows):
+            try:
+                total = 0.0
+                for entry in self._host_instruments:
+                    model_dat = entry["model"](th, entry["wave"])
+                    total += -0.5 * np.sum((entry["flux"] - model_dat) ** 2 * entry["inv_sigma2"] - entry["log_inv_sigma2"])
+                out[i] = total
+            except Exception:
+                out[i] = -np.inf
+        return out
+
+    def _prior_only(self, th2):
+        return np.atleast_1d(self.lnprior(th2)).astype(np.float64)
+
     def lnprob(self, theta):
-        """(D,) -> float, (W, D) -> (W,) float64: one GPU pass for the whole batch."""
+        """(D,) -> float, (W, D) -> (W,) float64: one GPU pass for the whole batch; instruments given as plain
+        callables (the reference's pass-through branch) add their term on the host, for the rows inside the prior box
+        only -- the reference does not evaluate any model for a row outside it (vfit_mcmc.py:350-351)."""
         th = np.asarray(theta, dtype=np.float64)
-        out = self.engine.lnprob(th)
+        if not self._host_instruments:
+            out = self.engine.lnprob(th)
+            return float(out[0]) if th.ndim == 1 else out
+        th2 = np.atleast_2d(th)
+        out = np.array(self.engine.lnprob(th2) if self._n_gpu else self._prior_only(th2), dtype=np.float64)
+        inside = ~np.isneginf(self._prior_only(th2))
+        if np.any(inside):
+            out[inside] = out[inside] + self._host_lnlike_rows(th2[inside])
         return float(out[0]) if th.ndim == 1 else out
 
     def lnlike(self, theta):
@@ -131,17 +197,20 @@ class vfit:
         box are evaluated here through a context-free detour: lnlike = lnprob where the prior is 0,
         and the model is evaluated explicitly for out-of-bounds rows."""
         th = np.atleast_2d(np.asarray(theta, dtype=np.float64))
-        out = self.engine.lnprob(th)
-        oob = np.isneginf(self.lnprior(th))
-        if np.any(oob):
-            out = out.copy()
+        out = np.array(self.engine.lnprob(th), dtype=np.float64) if self._n_gpu else np.zeros(len(th))
+        oob = np.isneginf(self._prior_only(th))
+        if np.any(oob) and self._n_gpu:
             rows = th[oob]
             total = np.zeros(len(rows))
             for entry in self.instrument_data.values():
+                if entry["index"] is None:
+                    continue
                 model = self.engine.model_flux(entry["index"], rows)
                 total += -0.5 * np.sum((entry["flux"] - model) ** 2 * entry["inv_sigma2"]
                                        - entry["log_inv_sigma2"], axis=1)
             out[oob] = total
+        if self._host_instruments:
+            out = out + self._host_lnlike_rows(th)
         return float(out[0]) if np.asarray(theta).ndim == 1 else out
 
     __call__ = lnprob
@@ -158,7 +227,7 @@ class vfit:
         D = theta.size
         h = np.where(theta + eps > self.ub, -eps, eps)
         batch = np.vstack([theta[None, :], theta[None, :] + np.diag(h)])
-        lp = self.engine.lnprob(batch)
+        lp = self.lnprob(batch)
         return float(lp[0]), (lp[1:] - lp[0]) / h
 
     def optimize_guess(self, theta, eps: float = 1e-8):
@@ -276,6 +345,9 @@ class vfit:
             import emcee
             sampler = emcee.EnsembleSampler(self.no_of_Chain, self.ndim, self.lnprob, vectorize=True)
             sampler.run_mcmc(guesses, self.no_of_steps, progress=verbose)
+        elif sampler in ("device", "device-slice") and self._host_instruments:
+            raise ValueError("sampler='device' / 'device-slice' keep the walker loop on the GPU; an instrument whose model is a "
+                             "Python callable is evaluated on the host: use 'emcee', 'zeus', 'host' or 'host-slice'")
         elif sampler == "device-slice":                # zeus' move with the whole walker loop on the GPU (vp_slice_run)
             from .sampler import DeviceSliceSampler
             sampler = DeviceSliceSampler(self.no_of_Chain, self.ndim, self.engine, seed=seed)

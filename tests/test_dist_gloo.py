@@ -10,6 +10,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+WS = (16, 10, 7, 3, 1)
+
+
+def _rows(z, W):
+    return np.concatenate([z["thetas"], z["thetas"][::-1] + 1e-4])[:W]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -28,35 +35,51 @@ def _worker(rank, world, port, q):
 
     post = ShardedPosterior(local_eval)
     res = {}
-    for W in (10, 7, 1):                       # even, ragged, fewer walkers than ranks
-        res[W] = post(z["thetas"][:W])
+    for W in WS:                               # even, ragged, fewer walkers than ranks
+        res[W] = post(_rows(z, W))
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, res, calls))
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_gloo_sharding_matches_serial():
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gloo_sharding_matches_serial(world):
+    """SURVEY 8e on CPU for world = 2, 4 and 8 (the node the scaling bench runs on): contiguous blocks of ceil(W / G) rows,
+    ranks past the end idle, every rank ends up with the whole vector -- also for batches of fewer rows than ranks."""
     import torch.multiprocessing as mp
     from oracle import voigt_oracle as vo
+    from rbvfit_amd.dist import shard_bounds
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + world * 131) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=240) for _ in procs]
+    out = [q.get(timeout=400) for _ in procs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     z = np.load(os.path.join(ROOT, "tests", "golden", "ragged_1000.npz"))
     insts = vo.instruments_from_fixture(z)
-    for W in (10, 7, 1):
-        ref = vo.lnprob_batch(z["thetas"][:W], z["lb"], z["ub"], insts)
+    for W in WS:
+        ref = vo.lnprob_batch(_rows(z, W), z["lb"], z["ub"], insts)
         for rank, res, calls in out:
             assert np.array_equal(res[W], ref, equal_nan=True)      # every rank holds the full vector
     calls = dict((r, c) for r, _, c in out)
-    assert calls[0] == [5, 4, 1] and calls[1] == [5, 3]             # blocks: ceil(W/2) rows, rank 1 idle at W=1
+    for r in range(world):
+        want = []
+        for W in WS:
+            lo, hi = shard_bounds(W, world, r)
+            if hi > lo:
+                want.append(hi - lo)
+        assert calls[r] == want, (r, calls[r], want)                # blocks of ceil(W / world) rows; idle ranks evaluate nothing
+        for W in WS:
+            lo, hi = shard_bounds(W, world, r)
+            B = -(-W // world)
+            assert (lo, hi) == (min(r * B, W), min((r + 1) * B, W))
+    if world == 2:
+        assert calls[0] == [8, 5, 4, 2, 1] and calls[1] == [8, 5, 3, 1]
 
 
 def _island_worker(rank, world, port, q):

@@ -275,6 +275,51 @@ def test_vfit_mirror_and_compiled_model_on_device():
         fit.close()
 
 
+def test_vfit_user_callable_instrument_mixed_with_gpu_instruments():
+    """SURVEY A4 (vfit_mcmc.py:242-248, 304): one instrument of a joint fit on the GPU, the other a plain Python callable
+    (here the oracle's model_flux: the reference's own arithmetic) evaluated on the host per row; -inf rows evaluate no
+    model, an exception inside a row makes that row -inf (vfit_mcmc.py:317-319)."""
+    from oracle import voigt_oracle as vo
+    from rbvfit_amd.model import CompiledModelData
+    from rbvfit_amd.vfit import vfit
+    z = load_golden("c3_mini")
+    insts = vo.instruments_from_fixture(z)
+
+    def tables(inst):
+        g = lambda k: z[f"{inst}__{k}"]
+        return CompiledModelData(g("lambda0"), g("gamma").astype(np.float32), g("f").astype(np.float32), g("zfac"), g("N_idx"),
+                                 g("b_idx"), g("v_idx"), g("taps"), int(g("lsf_mode")), len(g("lambda0")), len(z["lb"]) // 3, "wofz")
+
+    calls = []
+
+    def model_a(theta, wave):
+        calls.append(1)
+        return vo.model_flux(insts[0].data, theta, wave)
+
+    data = {"A": {"model": model_a, "wave": z["A__wave"], "flux": z["A__flux"], "error": z["A__error"]},
+            "B": {"model": tables("B"), "wave": z["B__wave"], "flux": z["B__flux"], "error": z["B__error"]}}
+    fit = vfit(data, z["theta_true"], z["lb"], z["ub"], no_of_Chain=12, no_of_steps=4)
+    try:
+        got = fit.lnprob(z["thetas"])
+        ref = z["lnprob"]
+        assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and len(calls) == int(np.sum(~np.isneginf(ref)))
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        np.testing.assert_allclose(fit.lnlike(z["thetas"][:3]), [vo.lnlike(t, insts) for t in z["thetas"][:3]], rtol=LNPROB_RTOL)
+        s = fit.runmcmc(seed=3, sampler="host")           # the host walker loop calls back into Python per row
+        assert np.all(np.isfinite(s.lnprobability))
+        with pytest.raises(ValueError):
+            fit.runmcmc(sampler="device")
+        data["A"]["model"] = lambda theta, wave: (_ for _ in ()).throw(RuntimeError("boom"))
+        fit2 = vfit(data, z["theta_true"], z["lb"], z["ub"])
+        try:
+            assert np.all(np.isneginf(fit2.lnprob(z["thetas"])))
+        finally:
+            fit2.close()
+    finally:
+        fit.close()
+
+
 def test_engine_argument_errors():
     import rbvfit_amd
     z = load_golden("one_px")

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import GOLDEN, load_golden
 from rbvfit_amd import atomic, LSF_SCIPY_NEAREST, LSF_ASTROPY_EXTEND, LSF_NONE
 from rbvfit_amd.lsf import gaussian_taps
 from rbvfit_amd.model import FitConfiguration, VoigtModel, mean_fwhm_pixels, tables_from_rbvfit
@@ -203,6 +203,133 @@ def test_vfit_validation_errors_match_the_reference():
         vfit._validate_guesses([1.0, 5.0], [0.0, 0.0], [2.0, 2.0])
     with pytest.raises(ValueError):
         vfit._validate_guesses([1.0], [0.0, 0.0], [2.0, 2.0])
+
+
+def _tables_from_fixture(z, inst):
+    from rbvfit_amd.model import CompiledModelData
+    g = lambda k: z[f"{inst}__{k}"]
+    gamma, f = g("gamma"), g("f")
+    if bool(g("gamma_is_f32")):
+        gamma, f = gamma.astype(np.float32), f.astype(np.float32)
+    C = len(z["lb"]) // 3
+    return CompiledModelData(g("lambda0"), gamma, f, g("zfac"), g("N_idx"), g("b_idx"), g("v_idx"), g("taps"),
+                             int(g("lsf_mode")), len(g("lambda0")), C, "fast" if int(g("voigt_method")) == 1 else "wofz")
+
+
+class _OracleEngine:
+    """Stands for rbvfit_amd.Engine in the CPU suite (the HIP engine needs a GPU): same calls, the oracle's arithmetic."""
+    def __init__(self, device_id=0):
+        self.inst = []
+
+    def set_bounds(self, lb, ub):
+        self.lb, self.ub = np.asarray(lb, float), np.asarray(ub, float)
+
+    def add_instrument(self, wave, flux, inv_sigma2, log_inv_sigma2, lambda0, gamma, f, zfac, N_idx, b_idx, v_idx,
+                       taps=None, lsf_mode=0, voigt_method=0):
+        from oracle import voigt_oracle as vo
+        d = vo.OracleModelData(lambda0, gamma, f, zfac, np.asarray(N_idx, np.int64), np.asarray(b_idx, np.int64),
+                               np.asarray(v_idx, np.int64), taps, lsf_mode, "fast" if voigt_method == 1 else "wofz")
+        self.inst.append(vo.OracleInstrument(d, wave, flux, inv_sigma2, log_inv_sigma2))
+        return len(self.inst) - 1
+
+    def lnprob(self, th):
+        from oracle import voigt_oracle as vo
+        return vo.lnprob_batch(th, self.lb, self.ub, self.inst)
+
+    def model_flux(self, idx, rows):
+        from oracle import voigt_oracle as vo
+        return np.array([vo.model_flux(self.inst[idx].data, t, self.inst[idx].wave) for t in np.atleast_2d(rows)])
+
+    def close(self):
+        pass
+
+
+def test_user_callable_instruments_are_evaluated_on_the_host(monkeypatch):
+    """SURVEY A4 / vfit_mcmc.py:242-248, 304: an instrument whose 'model' is any callable (theta, wave) -> flux is taken
+    verbatim; its likelihood term is added to the table-driven instruments'.  Rows outside the prior box evaluate no
+    model; any exception inside a row's likelihood makes that row -inf (vfit_mcmc.py:317-319)."""
+    from oracle import voigt_oracle as vo
+    import rbvfit_amd.vfit as V
+    monkeypatch.setattr(V, "Engine", _OracleEngine)
+    z = np.load(os.path.join(GOLDEN, "c3_mini.npz"), allow_pickle=False)
+    insts = vo.instruments_from_fixture(z)
+    calls = []
+
+    def model_b(theta, wave):                                    # a plain Python callable: the reference's pass-through branch
+        calls.append(np.array(theta, copy=True))
+        assert np.ndim(theta) == 1 and wave is not None
+        return vo.model_flux(insts[1].data, theta, wave)
+
+    data = {"A": {"model": _tables_from_fixture(z, "A"), "wave": z["A__wave"], "flux": z["A__flux"], "error": z["A__error"]},
+            "B": {"model": model_b, "wave": z["B__wave"], "flux": z["B__flux"], "error": z["B__error"]}}
+    fit = vfit(data, z["theta_true"], z["lb"], z["ub"])
+    assert fit.instrument_data["B"]["index"] is None and fit.instrument_data["A"]["index"] == 0
+    thetas = z["thetas"].copy()
+    thetas[3, 0] = z["lb"][0] - 1.0                              # outside the box: no model is evaluated for it
+    got = fit.lnprob(thetas)
+    want = vo.lnprob_batch(thetas, z["lb"], z["ub"], insts)
+    assert got[3] == -np.inf and len(calls) == int(np.sum(~np.isneginf(want))) < len(thetas)
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-13)
+    np.testing.assert_allclose(got[fin & (np.arange(len(got)) != 3)], z["lnprob"][fin & (np.arange(len(got)) != 3)], rtol=1e-10, atol=1e-7)
+    assert isinstance(fit.lnprob(thetas[0]), float) and fit.lnprob(thetas[0]) == got[0]
+    # lnlike: no prior, every row evaluated, the out-of-bounds one too
+    ll = fit.lnlike(thetas)
+    np.testing.assert_allclose(ll, [vo.lnlike(t, insts) for t in thetas], rtol=1e-13)
+    # chi2 counts both instruments' weights
+    const = sum(float(np.sum(np.asarray(i.log_inv_sigma2, float))) for i in insts)
+    np.testing.assert_allclose(fit.chi2(thetas[:2]), -2.0 * ll[:2] + const, rtol=1e-13)
+
+    # an exception in the callable -> that row's likelihood is -inf, the others are untouched
+    def model_raises(theta, wave):
+        if theta[0] > z["theta_true"][0]:
+            raise RuntimeError("model failed")
+        return vo.model_flux(insts[1].data, theta, wave)
+    data["B"]["model"] = model_raises
+    fit2 = vfit(data, z["theta_true"], z["lb"], z["ub"])
+    got2 = fit2.lnprob(z["thetas"])
+    bad = z["thetas"][:, 0] > z["theta_true"][0]
+    assert bad.any() and (~bad).any()
+    assert np.all(np.isneginf(got2[bad]))
+    np.testing.assert_allclose(got2[~bad], z["lnprob"][~bad], rtol=1e-10, atol=1e-7)
+    # NaN from the callable is NOT caught: it propagates (trap T7)
+    data["B"]["model"] = lambda theta, wave: np.full(wave.shape, np.nan)
+    assert np.all(np.isnan(vfit(data, z["theta_true"], z["lb"], z["ub"]).lnprob(z["thetas"][:2])))
+    # only callables: no table-driven instrument at all
+    only = vfit({"B": {"model": model_b, "wave": z["B__wave"], "flux": z["B__flux"], "error": z["B__error"]}},
+                z["theta_true"], z["lb"], z["ub"])
+    np.testing.assert_allclose(only.lnprob(z["thetas"][:3]), vo.lnprob_batch(z["thetas"][:3], z["lb"], z["ub"], insts[1:]), rtol=1e-13)
+    # the device-resident walker loops cannot call back into Python
+    with pytest.raises(ValueError):
+        fit.runmcmc(sampler="device")
+    # a bound model_flux of a compiled model (what the reference's own _compile_models stores) is NOT a host callable:
+    # its tables go to the engine and the method is never called on the host
+    from rbvfit_amd.model import CompiledVoigtModel
+    cm = CompiledVoigtModel(_tables_from_fixture(z, "B"))
+    data["B"]["model"] = cm.model_flux
+    fit3 = vfit(data, z["theta_true"], z["lb"], z["ub"])
+    assert fit3.instrument_data["B"]["index"] == 1 and not fit3._host_instruments
+    np.testing.assert_allclose(fit3.lnprob(z["thetas"][:3]), z["lnprob"][:3], rtol=1e-10, atol=1e-7)
+
+
+def test_normalize_kernel_default_follows_the_installed_astropy(monkeypatch):
+    """the mirror's Gaussian taps are raw (astropy 4.3.1, the pinned fixtures) unless the astropy
+    installed next to it normalises its Gaussian kernels; no astropy -> raw."""
+    import rbvfit_amd.model as M
+    cfg = FitConfiguration(); cfg.add_system(0.348, "MgII", [2796.35, 2803.53], 1)
+    z = load_golden("taps")
+    raw = z["fwhm_6.5"]
+    for answer, want_norm in ((None, False), (False, False), (True, True)):
+        monkeypatch.setattr(M, "_ASTROPY_NORMALIZES", answer)
+        m = VoigtModel(cfg, FWHM="6.5")
+        assert m.normalize_kernel is want_norm
+        assert (abs(m.taps.sum() - 1.0) < 1e-14) == want_norm
+        if not want_norm:
+            np.testing.assert_allclose(m.taps, raw, rtol=4e-16, atol=0)     # (exp of two libm builds: 1 ulp)
+    monkeypatch.setattr(M, "_ASTROPY_NORMALIZES", True)
+    assert abs(VoigtModel(cfg, FWHM="6.5", normalize_kernel=False).taps.sum() - 1.0) > 1e-6      # explicit choice wins
+    monkeypatch.setattr(M, "_ASTROPY_NORMALIZES", "unknown")
+    assert M.astropy_normalizes_gaussian() in (None, True, False)
 
 
 def test_tables_from_rbvfit_duck_typing():
