@@ -32,6 +32,24 @@
 
 namespace vp {
 
+// Diagnostic builds (-DVP_DIAG=<sum of ABL_* bits>, scripts/r5_ablate.sh): timing and instruction-count experiments whose RESULTS ARE
+// WRONG -- what a phase costs is read off the difference to the product build (profiles/r05_C1_budget.txt).  The product build has
+// VP_DIAG = 0: every `if (VP_ABL(..))` below is a compile-time false and leaves no trace in the kernels.
+#ifndef VP_DIAG
+#define VP_DIAG 0
+#endif
+enum { ABL_NOFAR = 1,       // no evaluation in the |x| >= 30 tiers (x and the tier decisions stay)
+       ABL_NONEAR = 2,      // none in the 8 <= |x| < 30 band: reference-rounded x + 9- / 14-term series
+       ABL_NOCORE = 4,      // no phase B (line cores)
+       ABL_NOEXP = 8,       // exp(-tau) -> 1 - tau
+       ABL_NOLSF = 16,      // the taps are not applied (the chi^2 terms are formed from zeros)
+       ABL_NOCHI = 32,      // nothing behind phase B: no LSF, no chi^2 terms
+       ABL_ENTRY = 64,      // walker_kernel ends behind its first barrier: what the entry costs alone
+       ABL_NOSMALLEXP = 128,  // no short Taylor form of exp where a chunk is shallow
+       ABL_NOPRIO = 256,      // no raised issue priority for waves with line cores
+       ABL_EMPTY = 512 };     // walker_kernel returns at once: what a launch of this shape costs
+#define VP_ABL(bit) ((VP_DIAG & (bit)) != 0)
+
 struct LinesDev {          // static per-instrument line tables (CompiledModelData, voigt_model.py:265-280)
     int L;
     const double* lambda0;
@@ -172,11 +190,6 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#ifdef VP_SHFL_WAVE_SUM
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-#else
     v += dpp_f64<0xB1, 0xf>(v);          // quad_perm [1,0,3,2]
     v += dpp_f64<0x4E, 0xf>(v);          // quad_perm [2,3,0,1]
     v += dpp_f64<0x141, 0xf>(v);         // row_half_mirror
@@ -184,7 +197,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_f64<0x142, 0xa>(v);         // row_bcast:15 into rows 1 and 3 (the other rows add the 0 of the masked move)
     v += dpp_f64<0x143, 0xc>(v);         // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-#endif
 }
 
 // Fill one record from (T, a).  ONE LANE PER RECORD: a wave prepares up to 64 records at once, so
@@ -838,7 +850,7 @@ constexpr int FL_PAD = 10;        // LDS doubles after a tile's flux that the ze
 // Stages: 0 entry, 1 records ready (behind the first barrier), 2 end of phase A, 3 end of phase B, 4 end of LSF + chi^2,
 // 5 behind the last barrier, 6 start of phase B (tiles with line cores), 7 HW_ID | XCC_ID << 32 (where the wave runs),
 // 8 kernel arguments have arrived, 9 theta row has arrived, 10 record tasks issued, 11 stores drained and preloads back.
-// Ablation builds (timing only, results are wrong): -DVP_ABL_NOFAR / NOCORE / NOLSF drop the |x| >= 30 tiers, phase B, the LSF.
+// (Ablation builds: VP_DIAG at the top of this file.)
 #ifdef VP_STAMPS
 constexpr int STAMP_W = 1024, STAMP_WAVES = 16, STAMP_STAGES = 16;
 __device__ long long g_stamps[STAMP_W * STAMP_WAVES * STAMP_STAGES];
@@ -1086,61 +1098,6 @@ __device__ __forceinline__ TilePre tile_preload(const InstDev& I, int p0, int no
     return pre;
 }
 
-// LSF + chi^2 (or flux output) for one block of 2 * CGN * nthreads output pixels starting at `ob`: each lane produces
-// CGN pairs of adjacent pixels from sliding windows of the flux held in registers.
-template <int CGN, int OUT>
-__device__ __forceinline__ void lsf_block(const InstDev& I, const double* __restrict__ fl, int kn, int ob, int nout, int p0, int w,
-                                          int tid, int nthreads, double* __restrict__ out, int out_stride, double& acc) {
-    int o0[CGN];
-    const double2* __restrict__ fw[CGN];
-    double m0[CGN], m1[CGN];
-#pragma unroll
-    for (int c = 0; c < CGN; ++c) {
-        o0[c] = ob + c * 2 * nthreads + 2 * tid;              // even
-        const int oc = min(o0[c], (nout - 1) & ~1);           // lanes past the end re-read the last pair
-        fw[c] = reinterpret_cast<const double2*>(fl + oc);
-        m0[c] = 0.0; m1[c] = 0.0;
-    }
-    for (int j = 0; j < kn; j += 8) {
-        rec_t kb = as_rec(I.kflip) + j;                       // uniform address: scalar loads, SGPR operands of the FMAs
-        double f[CGN][10];
-#pragma unroll
-        for (int c = 0; c < CGN; ++c) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const double2 v = fw[c][(j >> 1) + q];
-                f[c][2 * q] = v.x; f[c][2 * q + 1] = v.y;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double kj = kb[u];
-#pragma unroll
-            for (int c = 0; c < CGN; ++c) {
-                m0[c] = __builtin_fma(kj, f[c][u], m0[c]);
-                m1[c] = __builtin_fma(kj, f[c][u + 1], m1[c]);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CGN; ++c) {
-        const int p = p0 + o0[c];
-        if (OUT == 0) {
-            if (o0[c] < nout) {
-                const double d = I.flux[p] - m0[c];
-                acc = __builtin_fma(d * d, I.w[p], acc);      // (flux-model)^2 * inv_sigma2
-            }
-            if (o0[c] + 1 < nout) {
-                const double d = I.flux[p + 1] - m1[c];
-                acc = __builtin_fma(d * d, I.w[p + 1], acc);
-            }
-        } else {
-            if (o0[c] < nout) out[(size_t)w * out_stride + p] = m0[c];
-            if (o0[c] + 1 < nout) out[(size_t)w * out_stride + p + 1] = m1[c];
-        }
-    }
-}
-
 // LSF + chi^2 (or flux output) for one block of LSF_PX * nthreads output pixels starting at `ob`: each lane produces LSF_PX
 // CONSECUTIVE pixels from one sliding window of the flux held in registers -- per group of 8 taps 8 + LSF_PX - 1 doubles
 // read for 8 LSF_PX FMAs.  The phase is bound by LDS bandwidth, not by its FMAs (C2: 22 of the tile kernel's 102 us with
@@ -1354,9 +1311,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
 #pragma unroll
                     for (int r = 1; r < RB; ++r) xm = fmin(xm, fabs(x[r]));
                     if (VP_NONE_BELOW(xm, 30.0)) {        // the 1-FMA x is accurate enough out here
-#ifdef VP_ABL_NOFAR
-                        continue;
-#endif
+                        if (VP_ABL(ABL_NOFAR)) continue;
                         if (VP_NONE_BELOW(xm, 100.0)) {
                             if (VP_NONE_BELOW(xm, 3000.0)) wing_rb<2>(x, K, tau);
                             else if (VP_NONE_BELOW(xm, 500.0)) wing_rb<3>(x, K, tau);
@@ -1366,6 +1321,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                         }
                         continue;
                     }
+                    if (VP_ABL(ABL_NONEAR) && VP_NONE_BELOW(xm, X_CORE)) continue;
                     double xf[RB];
 #pragma unroll
                     for (int r = 0; r < RB; ++r) xf[r] = faithful_x(wv[r], g[r], rec);
@@ -1437,13 +1393,12 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int i = base + r * 64 + lane;
-#ifndef VP_NO_SMALL_EXP
+            if (VP_ABL(ABL_NOEXP)) { if (i < n_eval) fl[i] = 1.0 - tau[r]; continue; }
             // a chunk in the far wings of every line (|tau| < 2^-10 in all its lanes; a NaN fails the test): short Taylor form
-            if (!pending[r] && __ballot(!(fabs(tau[r]) < EXP_SMALL_MAX)) == 0ull) {
+            if (!VP_ABL(ABL_NOSMALLEXP) && !pending[r] && __ballot(!(fabs(tau[r]) < EXP_SMALL_MAX)) == 0ull) {
                 if (i < n_eval) fl[i] = exp_neg_small(tau[r]);
                 continue;
             }
-#endif
             // voigt_model.py:217; a NaN tau (NaN pixel, poisoned line) stays NaN as in the reference
             if (i < n_eval) fl[i] = (pending[r] || tau[r] != tau[r]) ? tau[r] : exp_neg_tab(tau[r], etab);
         }
@@ -1468,17 +1423,13 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
             }
             anyc = __ballot(anycore != 0u) != 0ull;
         }
-#ifdef VP_ABL_NOCORE
-        anyc = false;
-#endif
+        if (VP_ABL(ABL_NOCORE)) anyc = false;
         if (anyc) {
             if (!daw_ready) {                        // staged only when some chunk needs the core series
-#ifndef VP_NO_PRIO
                 // a wave with line cores has about twice the work of one without: it goes first on its SIMD from here on
                 // (walker_kernel: the workgroup's critical path; single-wave tile workgroups: longest jobs first,
                 // C1 at 1024 walkers 44.6 -> 43.0 us, neutral at 8192 and on C2-C4)
-                if (ONE || nwaves == 1) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
-#endif
+                if (!VP_ABL(ABL_NOPRIO) && (ONE || nwaves == 1)) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
                 dawson_to_lds(daw, tid, TILE_THREADS);
                 if (SOLO && tid == 0) I.core_hint[p0 / I.TP] = 1;      // (walker_kernel: next time, ahead of the records)
             }
@@ -1531,23 +1482,10 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     //      reads at most 9 doubles past the last one).  Per output the taps are still accumulated in ascending order, so the result is
     //      bit-identical to the plain loop.
     double acc = 0.0;
-#ifdef VP_ABL_NOLSF
-    if (OUT == 0) { VP_STAMP(4); return fl[tid]; }
-#endif
+    if (VP_ABL(ABL_NOCHI) && OUT == 0) { VP_STAMP(4); return fl[tid]; }
     if (OUT != 2) {
-        // blocks of 4 output pixels per lane (two pairs: ILP) while more than 2 per lane remain, then blocks of 2: the
-        // tail of a 362-pixel tile is one 128-pixel block instead of a mostly masked 256-pixel one.  Same pixels per
-        // lane and same order of additions as one block size throughout: results do not change.
-#ifdef VP_LSF_PAIRS
-        int ob = 0;
-        for (; nout - ob > 2 * TILE_THREADS; ob += 4 * TILE_THREADS)
-            lsf_block<2, OUT>(I, fl, Kp, ob, nout, p0, w, tid, TILE_THREADS, out, out_stride, acc);
-        for (; ob < nout; ob += 2 * TILE_THREADS)
-            lsf_block<1, OUT>(I, fl, Kp, ob, nout, p0, w, tid, TILE_THREADS, out, out_stride, acc);
-#else
         for (int ob = 0; ob < nout; ob += LSF_PX * TILE_THREADS)
-            lsf_block6<OUT, SOLO, W1>(I, fl, Kp, ob, nout, p0, w, tid, out, out_stride, acc);
-#endif
+            lsf_block6<OUT, SOLO, W1>(I, fl, VP_ABL(ABL_NOLSF) ? 0 : Kp, ob, nout, p0, w, tid, out, out_stride, acc);
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }
@@ -1909,10 +1847,12 @@ __device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int
         if (n == 8) {
             // the whole slot is one 64-byte line: ONE request brings the row and the word behind it (lane 63 asks for the word)
             row = __hip_atomic_load(slot + (lane == 63 ? 7 : dl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            flag = __builtin_amdgcn_readlane((unsigned int)row, 63) | ((unsigned long long)__builtin_amdgcn_readlane((unsigned int)(row >> 32), 63) << 32);
+            flag = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((unsigned int)row, 63) |
+                   ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((unsigned int)(row >> 32), 63) << 32);
         } else {
             flag = __hip_atomic_load(slot + n - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            flag = __builtin_amdgcn_readfirstlane((unsigned int)flag) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(flag >> 32)) << 32);
+            flag = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)flag) |
+                   ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(flag >> 32)) << 32);
             row = 0ull;
         }
         bool mine = ((unsigned int)flag >> 2) == A.arm_seq;
@@ -1924,8 +1864,8 @@ __device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int
             // not match yet is polled again (behind the keeper's look at the clock: a wait stays bounded whatever the slot holds)
             unsigned long long h = 0ull;
             for (int k = 0; k < A.D; ++k)
-                h ^= (unsigned long long)__builtin_amdgcn_readlane((unsigned int)row, k) |
-                     ((unsigned long long)__builtin_amdgcn_readlane((unsigned int)(row >> 32), k) << 32);
+                h ^= (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((unsigned int)row, k) |       // (readlane returns int: no sign extension)
+                     ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((unsigned int)(row >> 32), k) << 32);
             mine = (unsigned int)(h ^ (h >> 32)) == (unsigned int)(flag >> 32);
         }
         if (mine) {
@@ -2000,6 +1940,7 @@ template <int METHOD, bool CLUSTERS, bool SAMPLER, int NI, bool ARMED = false, i
 #endif
 __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, InstDev I3, WalkerMore tb, LinesDev T, WalkerArgs A, StretchArgs S) {
     extern __shared__ double smem[];
+    if (VP_ABL(ABL_EMPTY)) { if (threadIdx.x == 0 && A.lnprob) A.lnprob[blockIdx.x] = 0.0; return; }
     VP_STAMP_DECL
     VP_STAMP(0);
 #ifdef VP_STAMPS
@@ -2196,19 +2137,18 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         gs[14] = rt_entry; gs[12] = rt_go; gs[13] = wall_clock64();
     }
 #endif
-#ifndef VP_NO_PRIO
     // the tiles with line cores are the workgroup's critical path (twice the work of the others): their waves go first
     // on their SIMDs from the start where the hint says so, from phase B on otherwise
     // (only where two workgroups share the CU -- A.prio, set by the host for batches of more than one workgroup per CU: 512 walkers
     //  24.4 us without, 21.5 with; a workgroup that has its CU to itself measured 1 % slower with it: 256 walkers 15.68 / 15.50)
-    if (daw_ready && A.prio) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
-#endif
+    if (!VP_ABL(ABL_NOPRIO) && daw_ready && A.prio) __builtin_amdgcn_s_setprio(VP_PRIO_LEVEL);
     if (ARMED) {                                   // (told to leave, by the host or by the clock: nobody evaluates or writes anything)
         bool leave = false;
         for (int k = 0; k < min(ntask, nw); ++k) leave = leave || stash[k] != 1.0;
         if (leave) return;
     }
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
+    if (VP_ABL(ABL_ENTRY) && !SAMPLER && !FLUX) { if (tid == 0) walker_result(A, S.rep, w, 0.0); return; }
     if (oobw && !SAMPLER) {
         if (tid == 0) walker_result(A, S.rep, w, -__builtin_inf());
         return;

@@ -298,7 +298,7 @@ def test_vfit_user_callable_instrument_mixed_with_gpu_instruments():
 
     data = {"A": {"model": model_a, "wave": z["A__wave"], "flux": z["A__flux"], "error": z["A__error"]},
             "B": {"model": tables("B"), "wave": z["B__wave"], "flux": z["B__flux"], "error": z["B__error"]}}
-    fit = vfit(data, z["theta_true"], z["lb"], z["ub"], no_of_Chain=12, no_of_steps=4)
+    fit = vfit(data, z["theta_true"], z["lb"], z["ub"], no_of_Chain=48, no_of_steps=2)
     try:
         got = fit.lnprob(z["thetas"])
         ref = z["lnprob"]
