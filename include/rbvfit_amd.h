@@ -77,6 +77,12 @@ int vp_set_bounds(vp_ctx* ctx, int D, const double* lb, const double* ub);
  *   N_idx/b_idx/v_idx                      : theta indices per line (core/voigt_model.py:440-442)
  *   K, taps                                : kernel.array (K odd); K = 0 or taps = NULL with
  *                                            lsf_mode = VP_LSF_NONE means no LSF
+ * NaN wavelength samples: such a pixel's model is NaN in the reference.  With VP_LSF_SCIPY_NEAREST (and without an LSF) it poisons
+ * the outputs its taps reach and lnprob is NaN, as scipy's convolve1d does (:224).  With VP_LSF_ASTROPY_EXTEND the engine does what
+ * astropy's convolve does by default (nan_treatment='interpolate', :227,230): the NaN pixel is left out and every output is
+ * divided by the kernel weight of the samples that were used -- the pixel itself comes out as the weighted mean of its
+ * neighbours, lnprob stays finite; a gap of K or more consecutive NaN samples keeps NaN outputs (tests/golden/nan_wave_*.npz,
+ * nan_semantics.npz: vectors made by the reference).
  * Returns the instrument's index in *inst_index (may be NULL). */
 int vp_add_instrument(vp_ctx* ctx, int P, const double* wave, const double* flux,
                       const double* inv_sigma2, const double* log_inv_sigma2,
@@ -284,6 +290,11 @@ int vp_device_id(const vp_ctx* ctx);
  * 1 = walker_kernel (the whole batch in one launch: one instrument, or up to four with identical line tables), 2 = as 0 with farfield_kernel between preparation and tiles
  * (far lines from per-block expansions). */
 int vp_last_launch_kind(const vp_ctx* ctx);
+/* Workgroups per walker of the last walker_kernel launch: 0 = one (the ordinary form), 2 / 4 / 8 = its split form -- batches of at
+ * most one walker per compute unit (the reference's default is 50 walkers, vfit_mcmc.py:127-135) run every walker as several
+ * workgroups of one-pass tiles; option "walker_split" (-1 by batch size, 0 never, N always N).  A row's value is that of the
+ * one-pass tile launches (option "geom" = 1) bit for bit, whatever the number of groups. */
+int vp_last_walker_split(const vp_ctx* ctx);
 /* What the far-field expansions of the last lnprob batch covered (first instrument that took any; test / diagnosis hook, it
  * synchronises and copies the masks back): *variant = 0 none, 1 farfield_kernel<6,false> (lines outside clusters and whole
  * clusters, |x| >= 30), 2 farfield_kernel<9,true> (narrow-pixel instruments: also the MEMBERS of clusters too near for their

@@ -172,7 +172,23 @@ void vo_model_flux(const vo_inst* I, const double* theta, double* out, double* w
     {   /* true convolution, edge value replicated; astropy branch normalises the taps (:220-230) */
         const int K = I->K, c = K / 2;
         double norm = 1.0;
+        int any_nan = 0;
         if (I->lsf_mode == 2) { norm = 0; for (j = 0; j < K; ++j) norm += I->taps[j]; }
+        if (I->lsf_mode == 2) for (p = 0; p < P; ++p) any_nan |= fl[p] != fl[p];
+        if (any_nan) {
+            /* astropy convolve, nan_treatment='interpolate' (its default): top / bot over the window's non-NaN samples; a window
+               of NaNs only keeps the input value (tests/golden/nan_semantics.npz, nan_wave_custom.npz) */
+            for (p = 0; p < P; ++p) {
+                double top = 0, bot = 0;
+                for (j = K - 1; j >= 0; --j) {            /* ascending sample index, as the C loop of _convolveNd_c walks it */
+                    int q = p + c - j;
+                    q = q < 0 ? 0 : (q >= P ? P - 1 : q);
+                    if (fl[q] == fl[q]) { top += fl[q] * I->taps[j]; bot += I->taps[j]; }
+                }
+                out[p] = bot == 0 ? fl[p] : top / bot;
+            }
+            return;
+        }
         for (p = 0; p < P; ++p) {
             double s = 0;
             for (j = 0; j < K; ++j) {

@@ -100,11 +100,25 @@ def lsf_convolve(flux: np.ndarray, taps: np.ndarray, lsf_mode: int) -> np.ndarra
     if lsf_mode == LSF_NONE or taps is None or len(taps) == 0:
         return flux
     k = np.asarray(taps, dtype=np.float64)
-    if lsf_mode == LSF_ASTROPY_EXTEND:
-        k = k / k.sum()
     K = k.size
     c = K // 2
     padded = np.concatenate([np.full(c, flux[0]), flux, np.full(K - 1 - c, flux[-1])])
+    if lsf_mode == LSF_ASTROPY_EXTEND and np.isnan(flux.sum()):
+        # astropy.convolution.convolve's default nan_treatment='interpolate' (convolve.py:318, 374-389 of astropy 4.3.1; the C
+        # loop of _convolveNd_c): as soon as ANY sample is NaN every output is  top / bot  with
+        #   top = sum of val * ker,  bot = sum of ker   over the window's non-NaN samples
+        # -- a NaN sample is replaced by the kernel-weighted mean of its neighbours and the outputs around it are
+        # renormalised; an output whose whole window is NaN keeps the input's value (NaN).  Pinned by
+        # tests/golden/nan_semantics.npz and nan_wave_custom.npz (a NaN wavelength sample makes such a model pixel).
+        win = np.lib.stride_tricks.sliding_window_view(padded, K)          # win[p, j] = padded[p + j]
+        kf = k[::-1]                                                       # true convolution: kernel flipped
+        ok = ~np.isnan(win)
+        top = np.where(ok, win * kf, 0.0).sum(axis=1)
+        bot = np.where(ok, kf, 0.0).sum(axis=1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.where(bot == 0.0, flux, top / np.where(bot == 0.0, 1.0, bot))
+    if lsf_mode == LSF_ASTROPY_EXTEND:
+        k = k / k.sum()
     # np.convolve flips the kernel; 'valid' over the edge-padded signal gives P outputs
     return np.convolve(padded, k, mode="valid")
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vp_instrument_pixels": (C.c_int, [_ctx, C.c_int]),
     "vp_device_id": (C.c_int, [_ctx]),
     "vp_last_launch_kind": (C.c_int, [_ctx]),
+    "vp_last_walker_split": (C.c_int, [_ctx]),
     "vp_prearm_counts": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "vp_last_farfield_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "vp_last_error": (C.c_char_p, [_ctx]),

@@ -93,6 +93,9 @@ struct Tuning {
     int flux_walker = 1;        // vp_model_flux_batch[_device]: batches the walker kernel would take as lnprob batches as ONE launch (0: prep + tile launches)
     int stretch_mailbox = 1;    // vp_stretch_run's overlapped half-steps (stretch_overlap) keep a walker's row, lnprob and version in one 64-byte
                                 // line per buffer where D <= 6 (StretchArgs::ovl = 2); 0 = separate arrays
+    int walker_split = -1;      // walker_kernel's split form (WalkerArgs::split: a walker = several workgroups of one-pass tiles) for batches of at
+                                // most one walker per CU: -1 by batch size (2, 4 or 8 workgroups per walker: the fewest that put a
+                                // workgroup on every CU), 0 never, N > 0 always N (where the form applies at all)
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
                                 // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
@@ -109,7 +112,7 @@ const Knob g_knobs[] = {
     VP_KNOB(farfield, "RBVFIT_AMD_FARFIELD", 0), VP_KNOB(multi_sync, "RBVFIT_AMD_MULTI_SYNC", 0), VP_KNOB(tile_multi, "RBVFIT_AMD_TILE_MULTI", 0), VP_KNOB(no_ff_members, "RBVFIT_AMD_NO_FF_MEMBERS", 0), VP_KNOB(host_spin, "RBVFIT_AMD_HOST_SPIN", 0),
     VP_KNOB(tile_lpt, "RBVFIT_AMD_TILE_LPT", 0), VP_KNOB(gather_plain, "RBVFIT_AMD_GATHER_PLAIN", 0), VP_KNOB(slice_seg, "RBVFIT_AMD_SLICE_SEG", 0),
     VP_KNOB(flux_farfield, "RBVFIT_AMD_FLUX_FARFIELD", 0), VP_KNOB(stretch_overlap, "RBVFIT_AMD_STRETCH_OVERLAP", 0), VP_KNOB(stretch_mailbox, "RBVFIT_AMD_STRETCH_MAILBOX", 0), VP_KNOB(flux_walker, "RBVFIT_AMD_FLUX_WALKER", 0), VP_KNOB(walker_perm, "RBVFIT_AMD_WALKER_PERM", 0), VP_KNOB(walker_prio, "RBVFIT_AMD_WALKER_PRIO", 0), VP_KNOB(walker_perm_hex, "RBVFIT_AMD_WALKER_PERM_HEX", 1),
-    VP_KNOB(prearm, "RBVFIT_AMD_PREARM", 0), VP_KNOB(prearm_us, "RBVFIT_AMD_PREARM_US", 0),
+    VP_KNOB(prearm, "RBVFIT_AMD_PREARM", 0), VP_KNOB(prearm_us, "RBVFIT_AMD_PREARM_US", 0), VP_KNOB(walker_split, "RBVFIT_AMD_WALKER_SPLIT", 0),
 };
 void set_knob(Tuning& t, const Knob& k, long v) {
     char* base = reinterpret_cast<char*>(&t) + k.off;
@@ -129,6 +132,8 @@ struct Instrument {
     vp::InstDev dev_w{};         // walker_kernel's geometry: single-wave tiles of 384 evaluated pixels whatever the LSF
                                  // length (= dev for K <= 33; longer LSFs: more halo per tile, but one launch)
     size_t lds_w = 0;            // LDS bytes of one such tile; 0: the LSF is too long for single-wave tiles
+    size_t lds_s = 0;            // LDS bytes of one single-wave ONE-pass tile (dev_s where nwaves == 1): walker_kernel's split form; 0: none
+    int* split_hint = nullptr;   // (dev_s.ntiles) the split form's "tile met line cores before" hints (InstDev::core_hint of that launch)
     unsigned long long wperm = 0xFEDCBA9876543210ull;   // walker_kernel (this instrument alone): tile of wave k in nibble k (WalkerArgs)
 
     vp::LinesDev lines{};
@@ -141,6 +146,7 @@ struct Instrument {
     std::vector<double> h_lambda0, h_gamma;
     std::vector<int> h_bidx;
     bool needs_generic = true;
+    bool nanfix = false;         // astropy-branch LSF and NaN samples in the wavelength grid: InstDev::rbot (tile launches' NANFIX instances)
     int nwaves = 1;              // waves per tile workgroup (1, 2 or 4)
     bool ff_on = false;          // far-field expansions (farfield_kernel + the FF instance of tile_kernel) for lnprob
     double ff_cover = 0.0;       // estimated share of (block, line) pairs the expansions cover (host, prior-box centre)
@@ -252,6 +258,7 @@ struct vp_ctx {
     int policy_W = 0;            // > 0: the launch structure of a batch is chosen as for THIS many rows (a block of a larger batch
                                  // that other contexts share: same structure, hence the same bits, as the whole batch on one context)
     int last_kind = 0;           // launch structure of the last lnprob batch: 0 prep + tile (+ finalize), 1 walker_kernel
+    int last_split = 0;          // ... and, for walker_kernel, the workgroups per walker of its split form (0: the ordinary form)
     // the far-field expansions the last lnprob batch made for its FIRST instrument that took any (vp_last_farfield_info):
     // where they lie in the workspace, rows, blocks per row, which farfield_kernel instance, which instrument
     struct LastFF { const double* ff = nullptr; int W = 0, nbk = 0, members = 0, inst = -1; } last_ff;
@@ -377,7 +384,9 @@ int ensure_workspace(vp_ctx* c, int W) {
     if (ffblk > 0) HIP_TRY(c, hipMalloc((void**)&c->d_ff, (size_t)newW * ffblk * vp::FF_STRIDE * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_theta, (size_t)newW * std::max(c->D, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_out, (size_t)newW * sizeof(double)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_lc, (size_t)newW * maxL * vp::LC_STRIDE * sizeof(double)));
+    // (at least 1024 rows of records: walker_kernel's split form gives every workgroup of a walker its own rows -- W x split <= 512 --
+    //  and the stretch sampler keeps two half-steps in flight)
+    HIP_TRY(c, hipMalloc((void**)&c->d_lc, (size_t)std::max(newW, 1024) * maxL * vp::LC_STRIDE * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_partial, (size_t)newW * std::max(c->total_tiles, 1) * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->d_flags, (size_t)newW * sizeof(int)));
     HIP_TRY(c, hipMemset(c->d_flags, 0, (size_t)newW * sizeof(int)));
@@ -397,6 +406,19 @@ void launch_tile(const Instrument& in, const double* lc, const int* flags, doubl
     const vp::InstDev& dev = geom ? *geom : in.dev;
     dim3 grid(W, dev.ntiles, grid_z);
     dim3 block(64 * in.nwaves);
+    if (dev.rbot && OUT != 2) {           // NaN wavelength samples on the astropy branch: the instances that renormalise (InstDev::rbot)
+        constexpr int O = OUT == 1 ? 1 : 0;
+        if (GENERIC) {
+            const dim3 gg(gen_slots > 0 ? std::min(W, gen_slots) : W, dev.ntiles, grid_z);
+            hipLaunchKernelGGL((vp::tile_generic_kernel<O, false, true>), gg, block, in.lds_bytes, s, dev, lc, flags, out, stride, offset, fin, genflag, W,
+                               in.lines, (const double*)nullptr, 0);
+        } else if (dev.method == VP_VOIGT_FAST) {
+            hipLaunchKernelGGL((vp::tile_kernel<1, O, false, false, true>), grid, block, in.lds_bytes, s, dev, lc, flags, out, stride, offset, fin, genflag);
+        } else {
+            hipLaunchKernelGGL((vp::tile_kernel<0, O, false, false, true>), grid, block, in.lds_bytes, s, dev, lc, flags, out, stride, offset, fin, genflag);
+        }
+        return;
+    }
 #ifndef VP_NO_TILE1
     if (OUT == 0 && !GENERIC && in.nwaves == 1 && grid_z == 1) {        // single-wave tiles: the kernel compiled for them alone
         vp::Tile1Args a{dev, lc, flags, genflag, vp::TileTail{out, stride, offset, fin}};
@@ -539,6 +561,7 @@ bool walker_applies(const vp_ctx* c, int W) {
     if (c->tune.walker == 0 || c->inst.empty() || c->inst.size() > 4 || c->D > 64) return false;
     const Instrument& in = c->inst[0];
     for (auto& k : c->inst) {
+        if (k.nanfix) return false;          // (NaN wavelength samples on the astropy branch: the tile launches' NANFIX instances)
         if (k.lds_w == 0 || k.dev.method != in.dev.method) return false;
         if (k.dev.method == VP_VOIGT_WOFZ && k.needs_generic) return false;
     }
@@ -568,11 +591,66 @@ bool walker_applies(const vp_ctx* c, int W) {
     return layers <= per_cu && (layers <= 3 || layers <= per_cu - 2);
 }
 
+int walker_prio_for(vp_ctx* c, int W);
+int ctx_num_cus(vp_ctx* c) {
+    if (c->num_cus == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) c->num_cus = n;
+    }
+    return c->num_cus;
+}
+// walker_kernel's split form (WalkerArgs::split): how many workgroups a walker of a W-row batch gets, 0 = the ordinary form.
+// Where a batch leaves CUs without a workgroup the launch is as long as its heaviest wave's chain (profiles/r05_C1_budget.txt:
+// entry 5.0 + phase-A skeleton 3.0 + line cores 3.3 us of 15.5 at 256 walkers); one-pass tiles halve the chain behind the entry,
+// and several workgroups per walker put them on the idle CUs.  The fewest groups that give every CU a workgroup.
+int walker_split_for(vp_ctx* c, int W) {
+    if (c->tune.walker_split == 0 || c->inst.size() != 1 || c->tune.walker_clusters || c->gather_rep) return 0;
+    const Instrument& in = c->inst[0];
+    if (in.lds_s == 0 || !in.split_hint) return 0;
+    const int nt = in.dev_s.ntiles, ncu = ctx_num_cus(c);
+    int G = c->tune.walker_split;
+    if (G < 0) {
+        if (ncu <= 0 || W > ncu) return 0;
+        G = 2;
+        while ((long)W * G < ncu && G < 8) G *= 2;
+    }
+    G = std::min(G, nt);
+    if (G < 2 || (long)W * G > 1024) return 0;
+    const int nwpg = (nt + G - 1) / G;
+    if (nwpg > vp::WALKER_THREADS_MAX / 64) return 0;
+    if ((size_t)nwpg * in.lds_s + (size_t)(nwpg + 2 + 4 + 128) * sizeof(double) > c->lds_limit) return 0;
+    return G;
+}
+struct SplitShape { int G, waves; size_t lds; };
+SplitShape split_shape(const vp_ctx* c, int G) {
+    const Instrument& in = c->inst[0];
+    const int nwpg = (in.dev_s.ntiles + G - 1) / G;
+    return SplitShape{G, nwpg, (size_t)nwpg * in.lds_s + (size_t)(nwpg + 2 + 4 + 128) * sizeof(double)};
+}
+
 // (clusters: without their multipole records the members are ordinary lines -- a few more wing evaluations per pass
 // against a cluster preparation chain inside every workgroup)
+// split > 0: the split form -- W x split workgroups on the one-pass geometry; split_row0: first row of the tile-sum / ticket
+// workspace this launch may use (the record rows come with a.lc)
 template <bool SAMPLER, bool ARMED = false>
-void launch_walker_any(vp_ctx* c, int W, const vp::WalkerArgs& a, const vp::StretchArgs& st, hipStream_t s) {
+void launch_walker_any(vp_ctx* c, int W, vp::WalkerArgs a, const vp::StretchArgs& st, hipStream_t s, int split = 0, int split_row0 = 0) {
     const Instrument& in = c->inst[0];
+    if (split > 0) {
+        const SplitShape sh = split_shape(c, split);
+        vp::InstDev d0 = in.dev_s;
+        vp::LinesDev t0 = in.lines;
+        d0.NCm = 0; t0.NCm = 0;
+        d0.core_hint = in.split_hint;
+        d0.ff = nullptr;
+        a.wave_lds = (int)(in.lds_s / sizeof(double));
+        a.split = split; a.split_row0 = split_row0; a.split_part = c->d_partial; a.split_ticket = c->d_ticket;
+        a.wperm = 0xFEDCBA9876543210ull;
+        if (!SAMPLER) a.prio = walker_prio_for(c, W * split);
+        const dim3 grid(W * split), block(64 * sh.waves);
+        if (in.dev.method == VP_VOIGT_FAST) hipLaunchKernelGGL((vp::walker_kernel<1, false, SAMPLER, ARMED, 0, true>), grid, block, sh.lds, s, d0, t0, a, st);
+        else hipLaunchKernelGGL((vp::walker_kernel<0, false, SAMPLER, ARMED, 0, true>), grid, block, sh.lds, s, d0, t0, a, st);
+        return;
+    }
     const dim3 grid(W), block(64 * walker_tiles(c));
     const size_t lds = walker_lds_bytes(c);
     vp::InstDev d0 = in.dev_w;
@@ -642,16 +720,24 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
     }
     vp::StretchArgs st{};
     if (gather) st.rep = *gather;            // (the plain form's only use of the sampler arguments: where the results go)
-    if (armed) launch_walker_any<false, true>(c, W, a, st, s);
-    else launch_walker_any<false>(c, W, a, st, s);
+    const int split = gather ? 0 : walker_split_for(c, c->policy_W > 0 ? c->policy_W : W);
+    c->last_split = split;
+    if (armed) launch_walker_any<false, true>(c, W, a, st, s, split);
+    else launch_walker_any<false>(c, W, a, st, s, split);
 }
 
 // One stretch-move half-step of the active half (nS walkers) as ONE launch: proposal, lnprob and accept/reject inside
 // each walker's workgroup (walker_kernel<.., SAMPLER = true>).
 // (lc_row0: first row of the record workspace this launch may use -- two half-steps in flight at once, vp_stretch_run's
 //  overlapped form, must not share rows)
-void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStream_t s, int lc_row0 = 0) {
+void launch_walker_stretch(vp_ctx* c, int nS, const vp::StretchArgs& st, hipStream_t s, int lc_row0 = 0, int split = 0) {
     const size_t nrec = (size_t)(c->inst[0].dev.L + c->inst[0].dev.NCm) * vp::LC_STRIDE;
+    if (split > 0) {        // (every workgroup of a walker has its own record rows: the second launch in flight starts behind nS x split)
+        vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc + (size_t)lc_row0 * split * nrec, nullptr, c->inst[0].sum_logw, c->D, 0,
+                         (st.ovl && c->tune.walker_prio < 0) ? 1 : walker_prio_for(c, nS * split), 0ull};
+        launch_walker_any<true>(c, nS, a, st, s, split, lc_row0);
+        return;
+    }
     const vp::WalkerArgs a{nullptr, c->d_lb, c->d_ub, c->d_lc + (size_t)lc_row0 * nrec, nullptr, c->inst[0].sum_logw, c->D,
                            (int)(walker_wave_lds(c) / sizeof(double)),
                            (st.ovl && c->tune.walker_prio < 0) ? 1 : walker_prio_for(c, nS),     // (overlapped half-steps share the CUs)
@@ -704,7 +790,7 @@ int enqueue_lnprob(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         for (size_t k = 0; multi && k < ni; ++k) {
             const Instrument& in = c->inst[k];
             if (k > 0 && !in.same_lines_as_prev) multi = false;
-            if (in.lds_w == 0 || in.dev.method != c->inst[0].dev.method) multi = false;
+            if (in.lds_w == 0 || in.dev.method != c->inst[0].dev.method || in.nanfix) multi = false;
             if (in.needs_generic && in.dev.method == VP_VOIGT_WOFZ) multi = false;
             lds = std::max(lds, in.lds_w);
             waves += (long)Wp * in.dev_w.ntiles;
@@ -1063,14 +1149,22 @@ int vp_ctx_create(vp_ctx** out, int device_id) {
     for (const void* f : {(const void*)vp::walker_kernel<0, false, false>, (const void*)vp::walker_kernel<0, true, false>,
                           (const void*)vp::walker_kernel<1, false, false>, (const void*)vp::walker_kernel<0, false, true>,
                           (const void*)vp::walker_kernel<1, false, true>,
+                          (const void*)vp::walker_kernel<0, false, false, true>, (const void*)vp::walker_kernel<1, false, false, true>,
+                          (const void*)vp::walker_kernel<0, true, false, true>, (const void*)vp::walker_kernel<0, false, false, false, 1>,
+                          (const void*)vp::walker_kernel<0, false, false, false, 0, true>, (const void*)vp::walker_kernel<1, false, false, false, 0, true>,
+                          (const void*)vp::walker_kernel<0, false, true, false, 0, true>, (const void*)vp::walker_kernel<1, false, true, false, 0, true>,
+                          (const void*)vp::walker_kernel<0, false, false, true, 0, true>, (const void*)vp::walker_kernel<1, false, false, true, 0, true>,
+                          (const void*)vp::walker_kernel2<0, false, true>, (const void*)vp::walker_kernel2<1, false, true>,
+                          (const void*)vp::walker_kernel4<0, false, true>, (const void*)vp::walker_kernel4<1, false, true>,
+                          (const void*)vp::tile_kernel1<0, true>, (const void*)vp::tile_kernel1<0, false>, (const void*)vp::tile_kernel1<1, false>,
+                          (const void*)vp::tile_generic_kernel<0, false>, (const void*)vp::tile_generic_kernel<1, false>, (const void*)vp::tile_generic_kernel<1, true>,
+                          (const void*)vp::tile_generic_kernel<2, false>, (const void*)vp::tile_kernel<0, 1, false, true>,
                           (const void*)vp::walker_kernel2<0, false>, (const void*)vp::walker_kernel2<0, true>,
                           (const void*)vp::walker_kernel2<1, false>, (const void*)vp::walker_kernel2<1, true>,
                           (const void*)vp::walker_kernel4<0, false>, (const void*)vp::walker_kernel4<0, true>,
                           (const void*)vp::walker_kernel4<1, false>, (const void*)vp::walker_kernel4<1, true>,
                           (const void*)vp::tile_kernel<0, 0, false, true>, (const void*)vp::tile_kernel_multi<0>, (const void*)vp::tile_kernel_multi<1>,
-                          (const void*)vp::tile_kernel<0, 0, false>, (const void*)vp::tile_kernel<0, 0, true>,
-                          (const void*)vp::tile_kernel<0, 1, false>, (const void*)vp::tile_kernel<0, 1, true>,
-                          (const void*)vp::tile_kernel<0, 2, false>, (const void*)vp::tile_kernel<0, 2, true>,
+                          (const void*)vp::tile_kernel<0, 0, false>, (const void*)vp::tile_kernel<0, 1, false>, (const void*)vp::tile_kernel<0, 2, false>,
                           (const void*)vp::tile_kernel<1, 0, false>, (const void*)vp::tile_kernel<1, 1, false>,
                           (const void*)vp::tile_kernel<1, 2, false>})
         (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_limit);
@@ -1264,6 +1358,31 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
     d.span = span; d.TP = span - (Kuse - 1);
     d.ntiles = (P + d.TP - 1) / d.TP;
     d.wave = d_wave; d.ginv = d_ginv; d.flux = d_flux; d.w = d_w; d.kflip = d_k;
+    d.rbot = nullptr;
+    {
+        // NaN wavelength samples make NaN model pixels.  The reference's Gaussian branch (scipy convolve1d) lets each poison the K
+        // outputs around it; its CustomKernel branch (astropy convolve, nan_treatment='interpolate': voigt_model.py:227,230) leaves
+        // them out and divides every output by the kernel weight of the samples it did use.  The pattern is static, so the
+        // reciprocal of that weight is a per-pixel table (taps in the order the device applies them; a window of NaNs only: NaN).
+        bool any_nan = false;
+        for (int p = 0; p < P; ++p) any_nan |= wave[p] != wave[p];
+        if (any_nan && lsf_mode == VP_LSF_ASTROPY_EXTEND) {
+            std::vector<double> rbot(P);
+            const int halo = d.halo_lo;
+            for (int p = 0; p < P; ++p) {
+                double bot = 0.0;
+                for (int j = 0; j < Kuse; ++j) {
+                    const int q = std::min(std::max(p - halo + j, 0), P - 1);
+                    if (wave[q] == wave[q]) bot += kflip[j];
+                }
+                rbot[p] = bot != 0.0 ? 1.0 / bot : std::nan("");
+            }
+            double* d_rbot;
+            if ((rc = upload<double>(c, &in, rbot.data(), rbot.size(), &d_rbot))) { for (void* q : in.allocs) hipFree(q); return rc; }
+            d.rbot = d_rbot;
+            in.nanfix = true;
+        }
+    }
     d.core_hint = nullptr;                               // (per geometry, below)
     d.ff_tab = nullptr; d.ff = nullptr; d.ff_nblk = 0; d.ff_members = 0;
     in.dev_s = d;                                        // one-pass tiles for small batches (same LDS layout rules)
@@ -1275,7 +1394,7 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         }
     }
     // far-field expansions: per block of 64 RB evaluated pixels the centre and half-width of 1/wave (both geometries)
-    in.ff_on = voigt_method == VP_VOIGT_WOFZ && L <= 128 && (c->tune.farfield > 0 || (c->tune.farfield < 0 && L >= 8));
+    in.ff_on = voigt_method == VP_VOIGT_WOFZ && L <= 128 && (c->tune.farfield > 0 || (c->tune.farfield < 0 && L >= 8)) && !in.nanfix;
     if (in.ff_on) {
         for (vp::InstDev* gd : {&in.dev, &in.dev_s}) {
             const int blk_px = 64 * vp::RB, nblk = (gd->span + blk_px - 1) / blk_px;
@@ -1362,6 +1481,12 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
                 in.lds_w = 0;
             }
         }
+    }
+    // walker_kernel's split form runs on the ONE-pass geometry of single-wave tiles (dev_s), with hints of its own
+    if (in.nwaves == 1 && in.dev_s.span < in.dev.span && in.dev_s.ntiles >= 2 && c->tune.span == 0) {
+        in.lds_s = (size_t)(in.dev_s.span + vp::FL_PAD + 4 + vp::DAW_LDS_DOUBLES + vp::EXP_LDS_DOUBLES + (in.dev_s.span / 64) * ((L + 63) / 64)) * sizeof(double);
+        std::vector<int> zeros(std::max(in.dev_s.ntiles, vp::TILE_ORDER_AT), 0);
+        if ((rc = upload<int>(c, &in, zeros.data(), zeros.size(), &in.split_hint))) { for (void* p : in.allocs) hipFree(p); return rc; }
     }
     if (in.lds_bytes + (size_t)std::max(0l, c->tune.lds_pad) > c->lds_limit) {
         for (void* p : in.allocs) hipFree(p);
@@ -1749,6 +1874,8 @@ static int host_wait(vp_ctx* c) {
             // some workgroups of the expired launch may have met their rows and run: nothing of it may still write when the
             // rows are set to the pattern again
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            // (the split form counts a walker's workgroups in: groups of the expired launch that ran have left their tickets)
+            if (c->d_ticket && c->capW > 0) HIP_TRY(c, hipMemset(c->d_ticket, 0, (size_t)c->capW * sizeof(unsigned int)));
             std::memcpy(c->h_pinned, c->arm.theta_src, (size_t)W * c->D * sizeof(double));
             uint64_t* orow = const_cast<uint64_t*>(o);
             for (int k = 0; k < W; ++k) orow[k] = VP_SENTINEL_BITS;
@@ -2028,6 +2155,7 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
     // applies to a half-ensemble batch and the instrument has no cluster records
     const bool one_launch = !c->tune.no_fused_accept && c->tune.walker != 0 && walker_applies(c, half) &&
                             (c->inst[0].dev.NCm == 0 || !c->tune.walker_clusters);
+    const int split = one_launch ? walker_split_for(c, half) : 0;      // a walker of the half-step as several workgroups (WalkerArgs::split)
     const bool fuse = W <= 1024 && !c->tune.no_fused_accept;   // accept + next proposal in one launch
     const int wthr = ((W + 63) / 64) * 64;
     bool have_prop = false;                                   // is the proposal of the coming pass already enqueued?
@@ -2040,9 +2168,10 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
             int n = 0;
             if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) c->num_cus = n;
         }
-        const int nt = walker_tiles(c);
-        const long per_cu = std::max(1, std::min(24 / std::max(1, nt), (int)(c->lds_limit / walker_lds_bytes(c))));
-        ovl = c->tune.stretch_overlap > 0 || (per_cu >= 2 && 2l * half <= per_cu * (long)c->num_cus);
+        const int nt = split > 0 ? split_shape(c, split).waves : walker_tiles(c);
+        const size_t wl = split > 0 ? split_shape(c, split).lds : walker_lds_bytes(c);
+        const long per_cu = std::max(1, std::min((split > 0 ? 28 : 24) / std::max(1, nt), (int)(c->lds_limit / wl)));
+        ovl = c->tune.stretch_overlap > 0 || (per_cu >= 2 && 2l * half * std::max(1, split) <= per_cu * (long)c->num_cus);
         if (ovl && !c->stream2) {
             if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -2096,9 +2225,9 @@ int vp_stretch_run(vp_ctx* c, int W, int D, double* pos, double* lnprob, int hav
                         sa.pos_x = pb[k & 1]; sa.lp_x = lb2[k & 1];
                         sa.pos_w = pb[(k + 1) & 1]; sa.lp_w = lb2[(k + 1) & 1];
                         sa.pos_c = pb[(h ? k + 1 : k) & 1];
-                        launch_walker_stretch(c, half, sa, h ? s2 : s, h ? half : 0);
+                        launch_walker_stretch(c, half, sa, h ? s2 : s, h ? half : 0, split);
                     } else {
-                        launch_walker_stretch(c, half, sa, s);
+                        launch_walker_stretch(c, half, sa, s, 0, split);
                     }
                     continue;
                 }
@@ -2785,7 +2914,7 @@ int vp_multi_stretch_run(vp_multi* m, int W, int D, double* pos, double* lnprob,
                         sa.chain_pos = cp; sa.chain_lp = cl;
                         sa.a = a; sa.seed = seed; sa.step = step; sa.s0 = s0 + k0; sa.c0 = cc0; sa.nC = half; sa.half = h;
                         sa.rep = R;
-                        launch_walker_stretch(c, nk, sa, c->stream);
+                        launch_walker_stretch(c, nk, sa, c->stream, 0, walker_split_for(c, half));    // (the form the WHOLE half would get)
                     } else {
                         hipLaunchKernelGGL(vp::stretch_propose_block_kernel, dim3((nk + thr - 1) / thr), dim3(thr), 0, c->stream, d.pos, D, s0,
                                            half, cc0, half, a, seed, step, h, k0, nk, d.prop, d.zz, R);
@@ -2955,6 +3084,11 @@ int vp_last_launch_kind(const vp_ctx* c) {
     if (!c) return -1;
     std::lock_guard<std::mutex> g(c->mu);
     return c->last_kind;
+}
+int vp_last_walker_split(const vp_ctx* c) {
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->mu);
+    return c->last_kind == 1 ? c->last_split : 0;
 }
 
 }  // extern "C"

@@ -175,10 +175,12 @@ __device__ __forceinline__ void replicas_wait(const Replicas& R) {
 // count once more on a top word: 512 returning atomics on ONE word took the tail of a launch ~10 us (a word serves ~90 of them
 // per microsecond), 16 words of 32 do not queue.  R.done: PUB_GROUPS group counters, then the top one.
 constexpr unsigned int PUB_GROUPS = 16;
-__device__ __forceinline__ void replicas_publish(const Replicas& R, unsigned int nworkgroups) {
+// (index: this caller's number among the nworkgroups callers -- the workgroup's index, or the walker's where a walker is several
+//  workgroups of which one, the last to finish, calls: walker_kernel's split form)
+__device__ __forceinline__ void replicas_publish(const Replicas& R, unsigned int nworkgroups, unsigned int index) {
     if (!R.sync) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // this workgroup's rows before its count
-    const unsigned int g = blockIdx.x % PUB_GROUPS, ngroups = nworkgroups < PUB_GROUPS ? nworkgroups : PUB_GROUPS;
+    const unsigned int g = index % PUB_GROUPS, ngroups = nworkgroups < PUB_GROUPS ? nworkgroups : PUB_GROUPS;
     const unsigned int members = (nworkgroups - g + PUB_GROUPS - 1u) / PUB_GROUPS;          // workgroups w < nworkgroups with w % 16 == g
     if (__hip_atomic_fetch_add(R.done + g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != members - 1u) return;
     __hip_atomic_store(R.done + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -282,7 +284,7 @@ __global__ void stretch_accept_block_kernel(const double* __restrict__ pos_own, 
     }
     if (R.sync) {
         __syncthreads();
-        if (threadIdx.x == 0) replicas_publish(R, gridDim.x);
+        if (threadIdx.x == 0) replicas_publish(R, gridDim.x, blockIdx.x);
     }
 }
 

@@ -106,6 +106,10 @@ struct InstDev {
     int ff_nblk;           // blocks per tile = ceil(span / (64 RB))
     int ff_members;        // 1: members of clusters too near for their multipole may enter a block's expansion line by line (spectra
                            // whose blocks are a few Doppler widths wide: C4; pointless, and a little slower, on coarse grids)
+    const double* rbot;    // NULL, or (P): instruments on the astropy branch whose wavelength grid holds NaN samples (tile_work<..., NANFIX>):
+                           // astropy's convolve leaves NaN model pixels out and divides every output by the kernel weight it did use
+                           // (nan_treatment='interpolate', voigt_model.py:227,230) -- 1 / that weight per output pixel, made on the host
+                           // from the (static) NaN pattern; NaN where a whole window is NaN
     int* core_hint;        // (16) walker_kernel: tile t met line cores in an earlier launch -> its wave stages the Dawson
                            // table while it waits for the records instead of between phase A and phase B (a hint only:
                            // results never depend on it); behind them (TILE_ORDER_AT ...) tile_kernel's order of the
@@ -1105,8 +1109,9 @@ __device__ __forceinline__ TilePre tile_preload(const InstDev& I, int p0, int no
 // 48 B keeps the 16-byte reads conflict-free (8 lanes x 16 B cover the 32 banks once).  Per output the taps are
 // accumulated in ascending order, as in the plain loop.
 constexpr int LSF_PX = 6;
-template <int OUT, bool EARLY, bool LATE = false>    // EARLY: the observed pixels are requested ahead of the taps (walker_kernel, below)
+template <int OUT, bool EARLY, bool LATE = false, bool NANFIX = false>    // EARLY: the observed pixels are requested ahead of the taps (walker_kernel, below)
                                                      // LATE: spectrum and tap pointers re-read from the kernarg segment (tile_kernel1)
+                                                     // NANFIX: outputs times InstDev::rbot
 __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __restrict__ fl, int kn, int ob, int nout, int p0, int w,
                                            int tid, double* __restrict__ out, int out_stride, double& acc) {
     const int o0 = ob + LSF_PX * tid;                                         // even
@@ -1150,11 +1155,12 @@ __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __res
     for (int p = 0; p < LSF_PX; ++p) {
         const int px = p0 + o0 + p;
         if (o0 + p < nout) {
+            const double mp = NANFIX ? m[p] * I.rbot[px] : m[p];
             if (OUT == 0) {
-                const double d = (EARLY ? fobs[p] : pflux[px]) - m[p];
+                const double d = (EARLY ? fobs[p] : pflux[px]) - mp;
                 acc = __builtin_fma(d * d, EARLY ? wobs[p] : pw[px], acc);     // (flux-model)^2 * inv_sigma2
             } else {
-                out[(size_t)w * out_stride + px] = m[p];
+                out[(size_t)w * out_stride + px] = mp;
             }
         }
     }
@@ -1179,7 +1185,7 @@ __device__ __forceinline__ int next_near_line(unsigned long long nearm, int from
 //   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | exp table | per-chunk "line core" masks
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
 // fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
-template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false, bool FF = false, bool W1 = false>
+template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false, bool FF = false, bool W1 = false, bool NANFIX = false>
 __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
                                             int tid, int nthreads, const TilePre& pre, bool first,
                                             double* __restrict__ out, int out_stride VP_STAMP_ARG, bool daw_ready = false,
@@ -1483,9 +1489,20 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     //      bit-identical to the plain loop.
     double acc = 0.0;
     if (VP_ABL(ABL_NOCHI) && OUT == 0) { VP_STAMP(4); return fl[tid]; }
+    if (NANFIX && OUT != 2) {
+        // NaN wavelength samples (a static property of the grid) make NaN model pixels; the astropy branch leaves them out of the
+        // kernel-weighted mean: zero here, and the outputs are renormalised by InstDev::rbot in lsf_block6.  (A row whose theta
+        // is NaN is NaN in every other pixel as well and stays NaN, as in the reference.)
+        for (int i = tid; i < n_eval; i += TILE_THREADS) {
+            const int q = min(max(q0 + i, 0), I.P - 1);
+            const double wq = I.wave[q];
+            if (wq != wq) fl[i] = 0.0;
+        }
+        tile_sync<ONE>();
+    }
     if (OUT != 2) {
         for (int ob = 0; ob < nout; ob += LSF_PX * TILE_THREADS)
-            lsf_block6<OUT, SOLO, W1>(I, fl, VP_ABL(ABL_NOLSF) ? 0 : Kp, ob, nout, p0, w, tid, out, out_stride, acc);
+            lsf_block6<OUT, SOLO, W1, NANFIX>(I, fl, VP_ABL(ABL_NOLSF) ? 0 : Kp, ob, nout, p0, w, tid, out, out_stride, acc);
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }
@@ -1526,8 +1543,9 @@ __device__ __forceinline__ void publish_partial(const FinalizeArgs& F, double* _
 // Tile kernel: grid (W, tiles) x 64/128/256 threads, workgroup = walker x pixel tile; records come from a
 // prep_lines_kernel launch.  GENERIC = false skips walkers flagged in `genflag`, GENERIC = true processes
 // ONLY the flagged walkers: every (walker, tile) is handled by exactly one of the two launches.
-template <int METHOD, int OUT, bool GENERIC, bool FF = false>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
+template <int METHOD, int OUT, bool GENERIC, bool FF = false, bool NANFIX = false>   // OUT: 0 = chi^2 partial, 1 = convolved flux, 2 = unconvolved flux
                                                                 // FF: far lines come from the block's expansion (farfield_kernel)
+                                                                // NANFIX: InstDev::rbot (NaN wavelength samples on the astropy branch)
 __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(InstDev I, const double* __restrict__ lc,
                                                             const int* __restrict__ flags,
                                                             double* __restrict__ out, int out_stride,
@@ -1557,7 +1575,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(Ins
                                                out + (size_t)blockIdx.z * I.P, out_stride VP_STAMP_NONE);
         return;
     }
-    const double wsum = wave_sum(tile_work<METHOD, OUT, GENERIC, false, true, false, FF>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x,
+    const double wsum = wave_sum(tile_work<METHOD, OUT, GENERIC, false, true, false, FF, false, NANFIX>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x,
                                                                                          pre, true, out, out_stride VP_STAMP_NONE, false, t));
     if (OUT == 0) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -1577,7 +1595,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_kernel(Ins
 // C2 11 us per pass).  Its grid is therefore GEN_SLOTS x tiles: a workgroup walks the walkers slot, slot + GEN_SLOTS, ... and
 // evaluates its tile for the flagged ones, exactly as tile_kernel<0, OUT, true> did for its one (walker, tile).
 constexpr int GEN_SLOTS = 64;
-template <int OUT, bool REBUILD = false>      // REBUILD: behind walker_kernel's flux form (whole records are formed here first)
+template <int OUT, bool REBUILD = false, bool NANFIX = false>      // REBUILD: behind walker_kernel's flux form (whole records are formed here first)
 __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_generic_kernel(InstDev I, const double* __restrict__ lc,
                                                             const int* __restrict__ flags,
                                                             double* __restrict__ out, int out_stride,
@@ -1620,7 +1638,7 @@ __global__ __launch_bounds__(TILE_THREADS_MAX, VP_TILE_WPE) void tile_generic_ke
             __syncthreads();                         // (the LDS block is the next walker's)
             continue;
         }
-        const double wsum = wave_sum(tile_work<0, OUT, true, false, true, false, false>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x,
+        const double wsum = wave_sum(tile_work<0, OUT, true, false, true, false, false, false, NANFIX>(I, lcw, fl, p0, nout, w, threadIdx.x, blockDim.x,
                                                                                         pre, true, out, out_stride VP_STAMP_NONE, false, t));
         if (OUT == 0) {
             const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -1831,15 +1849,26 @@ struct WalkerArgs {
     int* genflag_clear;
     int* gen_any;
     int* gen_any_clear;
+    // Split form (walker_kernel<..., SPLIT = true>; batches that leave the GPU mostly idle: at most one walker per CU): a walker is
+    // `split` workgroups, each with the waves of a contiguous run of ONE-pass tiles (192 evaluated pixels: the tile launches'
+    // small-batch geometry, InstDev dev_s) -- half the chain per wave, and the walker's waves on several CUs.  Every workgroup forms
+    // the walker's records for itself (rows blockIdx.x of the record workspace) and applies the prior; the tile sums meet in
+    // `split_part` (W, tiles of the walker), and the workgroup that draws the walker's last ticket adds ALL of them in tile order --
+    // the sum does not depend on `split`, and equals the one-pass tile launches' bit for bit.  split_row0: first walker row of
+    // split_part / split_ticket this launch may use (two half-steps of the stretch sampler in flight at once).
+    int split;
+    int split_row0;
+    double* split_part;
+    unsigned int* split_ticket;
 };
 
 constexpr int ARM_GO = 1, ARM_LEAVE = 2;
 constexpr int ARM_EXPIRED_WORD = 16, ARM_STUCK_WORD = 32;      // (in units of 4 bytes: separate cache lines of the host block)
 // (wave-uniform) the decision for this workgroup; on ARM_GO `thv` holds the theta row across the lanes (lane >= D: the last parameter)
-__device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int lane, double& thv) {
+__device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int lane, double& thv, bool first_group, int nslots) {
     const int n = A.arm_slot_doubles;
     const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(A.arm_slots) + (size_t)w * n;
-    const bool keeper = w == 0 && wid == 0;          // the one wave that looks at the clock
+    const bool keeper = first_group && wid == 0;     // the one wave that looks at the clock (wave 0 of the launch's first workgroup)
     const long long t0 = keeper ? wall_clock64() : 0ll;
     const int dl = min(lane, A.D - 1);
     for (int spins = 0;; ++spins) {
@@ -1884,7 +1913,7 @@ __device__ __forceinline__ int arm_wait(const WalkerArgs& A, int w, int wid, int
             if (wall_clock64() - t0 > (long long)A.arm_ticks || spins > (1 << 22)) {     // (the count: should the clock ever stand still)
                 const unsigned long long leave = ((unsigned long long)A.arm_seq << 2) | (unsigned long long)ARM_LEAVE;
                 unsigned long long* all = reinterpret_cast<unsigned long long*>(const_cast<double*>(A.arm_slots));
-                for (int i = lane; i < (int)gridDim.x; i += 64) __hip_atomic_store(all + (size_t)i * n + n - 1, leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int i = lane; i < nslots; i += 64) __hip_atomic_store(all + (size_t)i * n + n - 1, leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (lane == 0) __hip_atomic_store(A.arm_host + ARM_EXPIRED_WORD, A.arm_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return ARM_LEAVE;
             }
@@ -1930,7 +1959,7 @@ __device__ __forceinline__ void walker_result(const WalkerArgs& A, const Replica
 // tiles of instrument k, Ik its geometry and spectrum, tb.slw[k-1] its weight constant; the tile sums are added per
 // instrument, in order, as finalize_kernel does.
 struct WalkerMore { int t[3]; double slw[3]; };
-template <int METHOD, bool CLUSTERS, bool SAMPLER, int NI, bool ARMED = false, int FLUX = 0>   // FLUX: the convolved model flux instead of lnprob
+template <int METHOD, bool CLUSTERS, bool SAMPLER, int NI, bool ARMED = false, int FLUX = 0, bool SPLIT = false>   // SPLIT: WalkerArgs::split.  FLUX: the convolved model flux instead of lnprob
                                        // (WalkerArgs::flux_stride ...).  ARMED: pre-armed launch (WalkerArgs::arm_*; an instance of
                                        // its own, so that the ordinary launch's entry is compiled without the wait).  CLUSTERS: the instrument has multipole cluster records (their
                                        // preparation needs more registers than the tile work and spills to scratch;
@@ -1956,13 +1985,16 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             g_stamps[(g_stamp_w * STAMP_WAVES + (int)(threadIdx.x >> 6)) * STAMP_STAGES + 7] = (long long)hwid | ((long long)xcc << 32);
     }
 #endif
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    // SPLIT: workgroup blockIdx.x is group sg of walker w; its rows of the record workspace are its own
+    const int wb = blockIdx.x;
+    const int w = SPLIT ? wb / A.split : wb, sg = SPLIT ? wb - w * A.split : 0;
+    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler knows it: the tile
                                                                    // geometry stays in SGPRs as in tile_kernel
     double* __restrict__ fl = smem + (size_t)wid * A.wave_lds;
     double* __restrict__ red = smem + (size_t)nw * A.wave_lds;      // nw tile sums, then the prior flag
     const int nrec = T.L + T.NCm;
-    double* __restrict__ lcw = A.lc + (size_t)w * nrec * LC_STRIDE;
+    double* __restrict__ lcw = A.lc + (size_t)wb * nrec * LC_STRIDE;
     // the theta row of this walker across the lanes of EVERY wave (D <= 64): read from the batch, or -- sampler
     // form -- formed here: z ~ g(z) on [1/a, a], partner j from the complementary half, Y = X_j - (X_j - X_k) z
     // (stretch_propose's arithmetic; every wave repeats the few instructions instead of waiting for one)
@@ -2044,7 +2076,11 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     VP_STAMP(9);
 #endif
     // (wave-uniform) which instrument this wave's tile belongs to
-    const int tw = (int)((A.wperm >> (4 * wid)) & 15ull);         // the tile (over all instruments) this wave evaluates
+    // the tile (over all instruments) this wave evaluates; SPLIT: tile sg * nw + wid of the walker, a wave past the walker's
+    // last tile has none (it still takes its share of the entry's tasks and of the barriers)
+    const int tw_all = SPLIT ? sg * nw + wid : (int)((A.wperm >> (4 * wid)) & 15ull);
+    const bool has_tile = !SPLIT || tw_all < I0.ntiles;
+    const int tw = SPLIT ? min(tw_all, I0.ntiles - 1) : tw_all;
     const int ki = (NI > 1 && tw >= tb.t[0]) ? ((NI > 2 && tw >= tb.t[1]) ? ((NI > 3 && tw >= tb.t[2]) ? 3 : 2) : 1) : 0;
     const InstDev& I = ki == 0 ? I0 : (ki == 1 ? I1 : (ki == 2 ? I2 : I3));
     const int lt = ki == 0 ? tw : tw - tb.t[ki - 1];              // tile of its instrument
@@ -2098,7 +2134,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
                     const int dl = min(lane, A.D - 1);
                     thv = 0.5 * (A.lb[dl] + A.ub[dl]);
                 } else {
-                    arm_code = arm_wait(A, w, wid, lane, thv);
+                    arm_code = arm_wait(A, w, wid, lane, thv, wb == 0, SPLIT ? (int)gridDim.x / A.split : (int)gridDim.x);
 #ifdef VP_STAMPS
                     rt_go = wall_clock64();
 #endif
@@ -2150,9 +2186,10 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
     const bool oobw = red[nw] != 0.0;              // out-of-bounds walker: the model is not evaluated
     if (VP_ABL(ABL_ENTRY) && !SAMPLER && !FLUX) { if (tid == 0) walker_result(A, S.rep, w, 0.0); return; }
     if (oobw && !SAMPLER) {
-        if (tid == 0) walker_result(A, S.rep, w, -__builtin_inf());
+        if (tid == 0 && sg == 0) walker_result(A, S.rep, w, -__builtin_inf());
         return;
     }
+    if (SPLIT && oobw && sg != 0) return;          // (sampler form: the walker's first group alone rejects the proposal)
     double total = 0.0;
     if (FLUX) {
         // a line outside the fast domain (the records' mode words, a lane each, every wave for itself): the generic launch's walker
@@ -2170,7 +2207,8 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             }
             return;
         }
-        (void)tile_work<METHOD, FLUX, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, A.lnprob, A.flux_stride VP_STAMP_PASS, daw_ready);
+        if (has_tile)
+            (void)tile_work<METHOD, FLUX, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, A.lnprob, A.flux_stride VP_STAMP_PASS, daw_ready);
         return;
     }
     if (!oobw) {
@@ -2178,12 +2216,34 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         // can be scheduled above it
         unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
         asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-        const double wsum = wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS, daw_ready));
-        if (lane == 0) red[tw] = wsum;
+        const double wsum = has_tile ? wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS, daw_ready)) : 0.0;
+        if (lane == 0) red[SPLIT ? wid : tw] = wsum;
         __syncthreads();
         VP_STAMP(5);
         VP_STAMP_RT(15);
         if (wid != 0) return;
+        if (SPLIT) {
+            // this group's tile sums into the walker's row, then the ticket: the group that draws the last one has all of them
+            // (hand-off by agent-scope atomics on both sides, as publish_partial) and adds them in TILE order -- whatever `split` is
+            const int nt = I0.ntiles;
+            double* __restrict__ row = A.split_part + (size_t)(A.split_row0 + w) * nt;
+            const int t0 = sg * nw;
+            if (lane < nw && t0 + lane < nt) __hip_atomic_store(row + t0 + lane, red[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned int ticket = 0u;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(A.split_ticket + A.split_row0 + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+            if (ticket != (unsigned int)(A.split - 1)) return;
+            double sk = 0.0;
+            for (int b = 0; b < nt; b += 64) {
+                const int t = b + lane;
+                const double v = t < nt ? __hip_atomic_load(row + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;     // (its own among them: drained above)
+                for (int k = 0; k < min(64, nt - b); ++k)
+                    sk += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+            }
+            if (lane == 0) __hip_atomic_store(A.split_ticket + A.split_row0 + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total += -0.5 * (sk - A.sum_logw);         // vfit_mcmc.py:309-311
+        } else {
         double sk = 0.0;
         const int n0 = NI > 1 ? tb.t[0] : nw;
         for (int k = 0; k < n0; ++k) sk += red[k];
@@ -2193,6 +2253,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             const int a0 = tb.t[j - 1], a1 = j + 1 < NI ? tb.t[j] : nw;
             for (int k = a0; k < a1; ++k) sj += red[k];
             total += -0.5 * (sj - tb.slw[j - 1]);
+        }
         }
     } else if (wid != 0) {
         return;
@@ -2250,13 +2311,13 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             if (lane < A.D) S.chain_pos[(size_t)ws * A.D + lane] = accept ? y : x;
             if (lane == 0) S.chain_lp[ws] = accept ? lnp : lp_old;
         }
-        if (S.rep.n > 0 && S.rep.sync && lane == 0) replicas_publish(S.rep, gridDim.x);
+        if (S.rep.n > 0 && S.rep.sync && lane == 0) replicas_publish(S.rep, SPLIT ? gridDim.x / A.split : gridDim.x, SPLIT ? w : blockIdx.x);
     }
 }
 
-template <int METHOD, bool CLUSTERS, bool SAMPLER, bool ARMED = false, int FLUX = 0>
+template <int METHOD, bool CLUSTERS, bool SAMPLER, bool ARMED = false, int FLUX = 0, bool SPLIT = false>
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel(InstDev I, LinesDev T, WalkerArgs A, StretchArgs S) {
-    walker_body<METHOD, CLUSTERS, SAMPLER, 1, ARMED, FLUX>(I, I, I, I, WalkerMore{}, T, A, S);
+    walker_body<METHOD, CLUSTERS, SAMPLER, 1, ARMED, FLUX, SPLIT>(I, I, I, I, WalkerMore{}, T, A, S);
 }
 template <int METHOD, bool SAMPLER, bool ARMED = false>
 __global__ __launch_bounds__(WALKER_THREADS_MAX, VP_WALKER_WPE) void walker_kernel2(InstDev I, InstDev I1, WalkerMore tb, LinesDev T, WalkerArgs A,

@@ -345,6 +345,13 @@ class Engine:
         return {1: "walker", 2: "tiles+farfield", 3: "tiles-multi"}.get(kind, "tiles")
 
     @property
+    def last_walker_split(self) -> int:
+        """Workgroups per walker of the last walker_kernel launch (``vp_last_walker_split``): 0 the ordinary form, 2 / 4 / 8 its
+        split form for batches of at most one walker per compute unit (option "walker_split")."""
+        self._guard()
+        return int(self._lib.vp_last_walker_split(self._ctx))
+
+    @property
     def last_farfield_info(self) -> dict:
         """What the far-field expansions of the last lnprob batch covered (``vp_last_farfield_info``): ``variant`` 'none',
         'lines+clusters' (farfield_kernel<6,false>) or 'members' (farfield_kernel<9,true>: narrow-pixel instruments, members

@@ -44,6 +44,22 @@ def main():
                   f"polls that found a slot not ready {cnt[2]}, helper pair items {cnt[3]}  (per walker: {cnt[0] / W:.1f}, {cnt[1] / W:.1f}, {cnt[2] / W:.1f}, {cnt[3] / W:.1f})")
         buf = np.zeros(NW * NWAVES * NST, dtype=np.int64)
         assert lib.vp_debug_read_stamps(buf.ctypes.data_as(C.POINTER(C.c_longlong)), buf.size) == 0
+        G = int(os.environ.get("TIMELINE_SPLIT", "0"))      # split form: rows are workgroups (walker * G + group); print group by group
+        if G:
+            assert eng.last_walker_split == G, eng.last_walker_split
+            allraw = buf.reshape(NW, NWAVES, NST)[:W * G, :NT, :]
+            for sg in range(G):
+                r = allraw[sg::G].astype(np.float64)
+                rel = (r - r[:, :, 0].min(axis=1)[:, None, None]) / 2400.0
+                rel[rel < 0] = np.nan
+                print(f"\n=== C1, {W} walkers x {G} groups, group {sg}: end of stage after the workgroup's first entry, us (mean over walkers), by wave")
+                print("    wave    entry  records   phaseA   phaseB      LSF    final  B-start        -  kernarg    theta  prepped  drained")
+                for t in range(NT):
+                    print(f"    {t:4d} " + " ".join(f"{np.nanmean(rel[:, t, k]):8.2f}" for k in range(12)))
+                life = (r[:, :, 5].max(axis=1) - r[:, :, 0].min(axis=1)) / 2400.0
+                print(f"    workgroup life: mean {np.nanmean(life):.2f} p90 {np.nanpercentile(life, 90):.2f} max {np.nanmax(life):.2f} us")
+            wl.engine.close()
+            continue
         raw = buf.reshape(NW, NWAVES, NST)[:W, :NT, :]
         hw = raw[:, :, 7]
         simd = (hw >> 4) & 3

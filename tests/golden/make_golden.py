@@ -282,5 +282,37 @@ def main():
                         astropy_extend=astropy_convolve(sig, CustomKernel(ker), boundary="extend"))
 
 
+def nan_cases():
+    """NaN wavelength samples: a NaN in the wavelength grid makes that model pixel NaN; the reference's
+    CustomKernel branch (astropy ``convolve``, default nan_treatment='interpolate', voigt_model.py:227,230) then replaces it by the
+    kernel-weighted mean of its finite neighbours and renormalises every output whose window holds a NaN, while the Gaussian
+    branch (scipy ``convolve1d``, :224) lets it poison K outputs -- and lnprob.  Two fixtures, one per branch, same spectrum."""
+    from astropy.convolution import convolve as astropy_convolve
+    theta_c0 = np.array([13.5, 13.2, 15.0, 25.0, -40.0, 20.0])
+    wave = np.linspace(3760.0, 3790.0, 700)
+    bad = [0, 137, 300, 301, 455, 456, 457, 699]          # isolated, pairs, a triple, both edges (boundary='extend' pads with them)
+    wave_nan = wave.copy()
+    wave_nan[bad] = np.nan
+    ker = np.array([0.02, 0.05, 0.12, 0.45, 0.2, 0.1, 0.04, 0.015, 0.005])      # asymmetric, sum != 1
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        build_case("nan_wave_custom", MGII, [("G", wave_nan, "6.5", ker)], theta_c0, 41, 10, 4)
+        build_case("nan_wave_gauss", MGII, [("G", wave_nan, "2.5", None)], theta_c0, 41, 8, 2)
+        rng = np.random.default_rng(6)
+        sig = rng.uniform(0.2, 1.0, 40)
+        sig[[0, 7, 8, 20, 21, 22, 39]] = np.nan
+        k7 = np.array([0.05, 0.1, 0.5, 0.2, 0.1, 0.03, 0.02])
+        wide = sig.copy(); wide[10:19] = np.nan                                  # a gap wider than the kernel: NaN survives
+        np.savez_compressed(os.path.join(HERE, "nan_semantics.npz"), signal=sig, kernel=k7, signal_wide_gap=wide,
+                            astropy_extend=astropy_convolve(sig, CustomKernel(k7), boundary="extend"),
+                            astropy_extend_wide_gap=astropy_convolve(wide, CustomKernel(k7), boundary="extend"))
+    print("nan_semantics: written")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "nan":
+        nan_cases()
+    else:
+        main()
+        nan_cases()

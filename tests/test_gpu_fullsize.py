@@ -275,6 +275,62 @@ def test_vfit_mirror_and_compiled_model_on_device():
         fit.close()
 
 
+def test_walker_kernel_split_form_small_batches():
+    """Batches of at most one walker per compute unit -- the reference's default is 50 walkers (vfit_mcmc.py:127-135) -- run every
+    walker as 2, 4 or 8 workgroups of one-pass tiles (WalkerArgs::split).  Checked on C1: the number of groups by batch size,
+    every row against the oracle, and bit for bit against (i) any other number of groups, (ii) the one-pass tile launches
+    (option "geom" = 1), (iii) the same row in a batch of another size, (iv) the same batch through the host entry with and
+    without the pre-armed launch; -inf rows and a NaN row among them."""
+    from rbvfit_amd.workloads import make_workload
+    wl = make_workload("C1", walkers=256)
+    vo, insts = _oracle_instruments(wl)
+    e = wl.engine
+    try:
+        th = wl.thetas.copy()
+        th[5, 0] = wl.lb[0] - 0.5                          # outside the box
+        th[9, 2] = np.nan                                  # NaN parameter: NaN lnprob (trap T7)
+        th[250, 4] = wl.ub[4] + 1.0
+        e.set_option("walker", 0); e.set_option("geom", 1); e.set_option("finalize", 0)
+        tiles = e.lnprob(th)
+        assert e.last_launch_kind == "tiles"
+        e.set_option("walker", -1); e.set_option("geom", -1); e.set_option("finalize", -1)
+        want_groups = {256: 2, 200: 2, 128: 2, 100: 4, 64: 4, 50: 8, 32: 8, 7: 8, 1: 8}
+        for W, G in want_groups.items():
+            got = e.lnprob(th[:W])
+            assert e.last_launch_kind == "walker" and e.last_walker_split == G, (W, e.last_launch_kind, e.last_walker_split)
+            assert np.array_equal(got, tiles[:W], equal_nan=True), W
+        assert np.isneginf(tiles[5]) and np.isneginf(tiles[250]) and np.isnan(tiles[9])
+        rows = [0, 1, 5, 9, 17, 100, 255]
+        ref = vo.lnprob_batch(th[rows], wl.lb, wl.ub, insts)
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(tiles[rows][fin], ref[fin], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        for G in (2, 4, 8, 0):
+            e.set_option("walker_split", G)
+            got = e.lnprob(th)
+            assert e.last_walker_split == G
+            if G:
+                assert np.array_equal(got, tiles, equal_nan=True)
+            else:                                          # the ordinary form sums two-pass tiles: the last bit may differ
+                ok = np.isfinite(tiles)
+                np.testing.assert_allclose(got[ok], tiles[ok], rtol=4e-16, atol=0)
+        e.set_option("walker_split", -1)
+        e.set_option("prearm", 1)                           # the split form behind a pushed-to launch
+        for _ in range(4):
+            assert np.array_equal(e.lnprob(th[:64]), tiles[:64], equal_nan=True)
+        assert e.prearm_counts["used"] >= 2
+        e.set_option("prearm", -1)
+        # 257 walkers: more than one per CU -- the ordinary form
+        big = np.concatenate([th, th[:1]])
+        e.lnprob(big)
+        assert e.last_launch_kind == "walker" and e.last_walker_split == 0
+        # the device-resident stretch move on the split form: chain identical to the host loop's replay of the same draws is
+        # covered in test_gpu_sampler (half-ensembles of <= 256 walkers take it by themselves); here: it runs and moves
+        pos, lp, *_ = e.stretch_run(wl.thetas[:64], 20, seed=5, store_chain=False)
+        np.testing.assert_array_equal(lp, e.lnprob(pos))
+    finally:
+        wl.engine.close()
+
+
 def test_vfit_user_callable_instrument_mixed_with_gpu_instruments():
     """SURVEY A4 (vfit_mcmc.py:242-248, 304): one instrument of a joint fit on the GPU, the other a plain Python callable
     (here the oracle's model_flux: the reference's own arithmetic) evaluated on the host per row; -inf rows evaluate no

@@ -82,8 +82,19 @@ def test_random_configuration(seed):
         for k, v in (("walker", 0), ("geom", 0), ("finalize", 0)):   # the two-pass tile geometry and the separate
             e.set_option(k, v)                                         # final reduction (large batches) as well
         got_big = e.lnprob(thetas)
-        e.set_option("walker", 1)                                      # and the one-launch walker kernel where it applies
+        e.set_option("walker", 1)                                      # and the one-launch walker kernel where it applies:
+        e.set_option("walker_split", 0)                                # a walker as ONE workgroup of two-pass tiles ...
         got_walker = e.lnprob(thetas)
+        was_walker = e.last_launch_kind == "walker"
+        got_split = {}
+        for G in (-1, 2, 4, 8):                                        # ... and as several workgroups of one-pass tiles (small batches)
+            e.set_option("walker_split", G)
+            r = e.lnprob(thetas)
+            if e.last_launch_kind == "walker" and e.last_walker_split > 0:
+                got_split[G] = (r, e.last_walker_split)
+        e.set_option("walker_split", -1)
+        e.set_option("walker", 0); e.set_option("geom", 1); e.set_option("finalize", 0)
+        got_small = e.lnprob(thetas)                                   # the one-pass tile launches: the split form's geometry
         for k in ("walker", "geom", "finalize"):
             e.set_option(k, -1)
         fl = e.model_flux(0, thetas[:3])
@@ -93,6 +104,14 @@ def test_random_configuration(seed):
     clustered = any(g.components >= 3 for s in model.config.systems for g in s.ion_groups)
     same_tiles = data.taps is None or data.taps.size <= 33     # (longer LSFs: 2-/4-wave tile workgroups in the launches,
                                                                # single-wave tiles in the walker kernel)
+    np.testing.assert_allclose(got_small, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+    for G, (r, used) in got_split.items():
+        assert was_walker and (G < 0 or used <= G)
+        np.testing.assert_allclose(r, ref, rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
+        # the sum over a walker's tiles is taken in tile order by the group that finishes last: independent of the number of groups
+        np.testing.assert_array_equal(r, got_split[min(got_split)][0])
+        if data.n_lines < 8 and not clustered:
+            np.testing.assert_array_equal(r, got_small)        # ... and that of the one-pass tile launches, bit for bit
     if data.n_lines < 8 and not clustered and same_tiles:
         np.testing.assert_array_equal(got_walker, got_big)     # same tiles, same summation order: bit-identical
     else:       # the tile launches use multipole expansions of clusters (>= 3 components of a transition) and, from 8 lines

@@ -20,16 +20,21 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # segment (0 = none); lds: static group segment bytes (the tile / walker kernels take ALL their LDS dynamically: 0)
 PINS = {
     # C1 headline: one launch per batch.  <= 80 VGPRs = six waves per SIMD = two 12-wave walkers per CU
-    "void vp::walker_kernel<0, false, false, false, 0>(": dict(vgpr=80, scratch=0, lds=0),
+    "void vp::walker_kernel<0, false, false, false, 0, false>(": dict(vgpr=80, scratch=0, lds=0),
     # ... its stretch-move, pre-armed and flux forms
-    "void vp::walker_kernel<0, false, true, false, 0>(": dict(vgpr=80, scratch=0, lds=0),
-    "void vp::walker_kernel<0, false, false, true, 0>(": dict(vgpr=80, scratch=0, lds=0),
-    "void vp::walker_kernel<0, false, false, false, 1>(": dict(vgpr=80, scratch=32, lds=0),
+    "void vp::walker_kernel<0, false, true, false, 0, false>(": dict(vgpr=80, scratch=0, lds=0),
+    "void vp::walker_kernel<0, false, false, true, 0, false>(": dict(vgpr=80, scratch=0, lds=0),
+    "void vp::walker_kernel<0, false, false, false, 1, false>(": dict(vgpr=80, scratch=32, lds=0),
+    # ... and the split form (several workgroups of one-pass tiles per walker: up to 13 waves per workgroup, two per CU need
+    # <= 72 VGPRs = seven waves per SIMD)
+    "void vp::walker_kernel<0, false, false, false, 0, true>(": dict(vgpr=72, scratch=0, lds=0),
+    "void vp::walker_kernel<0, false, true, false, 0, true>(": dict(vgpr=72, scratch=0, lds=0),
+    "void vp::walker_kernel<0, false, false, true, 0, true>(": dict(vgpr=72, scratch=0, lds=0),
     # C2-C4: single-wave tiles, 7 waves per SIMD at <= 72
     "void vp::tile_kernel1<0, true>(": dict(vgpr=72, scratch=0, lds=0),
     "void vp::tile_kernel1<0, false>(": dict(vgpr=72, scratch=0, lds=0),
-    "void vp::tile_kernel<0, 0, false, true>(": dict(vgpr=72, scratch=0, lds=0),
-    "void vp::tile_kernel<0, 0, false, false>(": dict(vgpr=72, scratch=0, lds=0),
+    "void vp::tile_kernel<0, 0, false, true, false>(": dict(vgpr=72, scratch=0, lds=0),
+    "void vp::tile_kernel<0, 0, false, false, false>(": dict(vgpr=72, scratch=0, lds=0),
     # far-field expansions: 4 waves per SIMD at <= 128
     "void vp::farfield_kernel<6, false>(": dict(vgpr=112, scratch=0, lds=0),
     "void vp::farfield_kernel<9, true>(": dict(vgpr=112, scratch=0, lds=0),

@@ -97,6 +97,25 @@ def test_convolution_semantics_asymmetric_kernel():
     np.testing.assert_allclose(got2, z["astropy_extend"], rtol=0, atol=4e-16)
 
 
+def test_astropy_branch_interpolates_nan_samples():
+    """voigt_model.py:227,230: astropy's convolve (CustomKernel / COS branch) runs with its default
+    nan_treatment='interpolate' -- NaN samples are left out and every output is renormalised by the kernel weight that was
+    used; a gap wider than the kernel keeps its NaN.  The scipy (Gaussian) branch poisons K outputs.  Reference-made vectors:
+    tests/golden/nan_semantics.npz, nan_wave_custom.npz, nan_wave_gauss.npz (make_golden.py nan)."""
+    z = load_golden("nan_semantics")
+    for sig, ref in (("signal", "astropy_extend"), ("signal_wide_gap", "astropy_extend_wide_gap")):
+        got = vo.lsf_convolve(z[sig], z["kernel"], vo.LSF_ASTROPY_EXTEND)
+        assert np.array_equal(np.isnan(got), np.isnan(z[ref]))
+        np.testing.assert_allclose(got[~np.isnan(got)], z[ref][~np.isnan(z[ref])], rtol=0, atol=4e-16)
+    assert np.isnan(z["astropy_extend_wide_gap"]).sum() == 3 and not np.isnan(z["astropy_extend"]).any()
+    poisoned = vo.lsf_convolve(z["signal"], z["kernel"], vo.LSF_SCIPY_NEAREST)
+    assert np.isnan(poisoned).sum() > np.isnan(z["signal"]).sum()
+    zc, zg = load_golden("nan_wave_custom"), load_golden("nan_wave_gauss")
+    assert np.isnan(zc["G__wave"]).sum() == 8 and not np.isnan(zc["G__model_flux"]).any()
+    assert np.isfinite(zc["lnprob"][:8]).all() and np.isneginf(zc["lnprob"][8:]).all()
+    assert np.isnan(zg["lnprob"][:6]).all() and np.isneginf(zg["lnprob"][6:]).all()
+
+
 def test_fast_method_is_bug_compatible_in_far_wings():
     """Trap T9: the 'fast' wings fall as x^-6; pixel 0 of C1 differs visibly from wofz."""
     zf = load_golden("c0_mgii_fast")
