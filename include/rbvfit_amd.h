@@ -78,7 +78,7 @@ int vp_set_bounds(vp_ctx* ctx, int D, const double* lb, const double* ub);
  *   K, taps                                : kernel.array (K odd); K = 0 or taps = NULL with
  *                                            lsf_mode = VP_LSF_NONE means no LSF
  * NaN wavelength samples: such a pixel's model is NaN in the reference.  With VP_LSF_SCIPY_NEAREST (and without an LSF) it poisons
- * the outputs its taps reach and lnprob is NaN, as scipy's convolve1d does (:224).  With VP_LSF_ASTROPY_EXTEND the engine does what
+ * exactly the outputs its K taps reach and lnprob is NaN, as scipy's convolve1d does (:224).  With VP_LSF_ASTROPY_EXTEND the engine does what
  * astropy's convolve does by default (nan_treatment='interpolate', :227,230): the NaN pixel is left out and every output is
  * divided by the kernel weight of the samples that were used -- the pixel itself comes out as the weighted mean of its
  * neighbours, lnprob stays finite; a gap of K or more consecutive NaN samples keeps NaN outputs (tests/golden/nan_wave_*.npz,
@@ -131,13 +131,19 @@ int vp_lnprob_batch_device(vp_ctx* ctx, int W, int D, const double* d_theta, dou
  *                       when world == 1.  1 <= world <= 8.
  *   vp_gather_connect   handles_all: world x 2 x 64 bytes, rank-major (this rank's own entry is not opened).  shared_device != 0:
  *                       some ranks share a GPU -- a launch that waits for its peers inside its workgroups needs their launches
- *                       to start while it holds its wave slots, which one GPU cannot promise to several ranks; the handshake is
- *                       then a one-wave launch of its own in front of every pass.
+ *                       to start while it holds its wave slots, which one GPU cannot promise to several ranks; a pass is then
+ *                       [one-wave launch that waits for the peers' flags of the pass before] [the pass] [one-wave launch that
+ *                       raises this rank's flag of this pass in every peer]: every wait depends on earlier-enqueued work only.
  *   vp_gather_wait      enqueues a one-wave kernel that returns once every rank's block of the LAST pass has landed here.
  *   vp_gather_state     the device pointer of this rank's (world, W) vector; *timed_out != 0 if a device-side wait gave up
  *                       (~ a second of polling: a peer that never ran), synchronises.  Either pointer may be NULL. */
 int vp_gather_create(vp_ctx* ctx, int W, int world, int rank, void* handles_out);
 int vp_gather_connect(vp_ctx* ctx, const void* handles_all, int shared_device);
+/* The same for ranks that are contexts of ONE process (several GPUs driven by one process, or -- tests -- several contexts on one
+ * GPU: a process cannot open its own IPC handles): peers[r] is rank r's context (this rank's own entry is ignored), each with a
+ * gather of the same W and world already created; their vectors are used through their device pointers (peer access between the
+ * devices is enabled where it is not).  Every rank calls it; the peers must outlive this rank's gather. */
+int vp_gather_connect_local(vp_ctx* ctx, vp_ctx* const* peers, int shared_device);
 int vp_lnprob_gather_device(vp_ctx* ctx, int W, int D, const double* d_theta, void* hip_stream);
 int vp_gather_wait(vp_ctx* ctx, void* hip_stream);
 int vp_gather_state(vp_ctx* ctx, double** d_gathered, int* timed_out);
@@ -290,10 +296,11 @@ int vp_device_id(const vp_ctx* ctx);
  * 1 = walker_kernel (the whole batch in one launch: one instrument, or up to four with identical line tables), 2 = as 0 with farfield_kernel between preparation and tiles
  * (far lines from per-block expansions). */
 int vp_last_launch_kind(const vp_ctx* ctx);
-/* Workgroups per walker of the last walker_kernel launch: 0 = one (the ordinary form), 2 / 4 / 8 = its split form -- batches of at
- * most one walker per compute unit (the reference's default is 50 walkers, vfit_mcmc.py:127-135) run every walker as several
- * workgroups of one-pass tiles; option "walker_split" (-1 by batch size, 0 never, N always N).  A row's value is that of the
- * one-pass tile launches (option "geom" = 1) bit for bit, whatever the number of groups. */
+/* Workgroups per walker of the last walker_kernel launch: 0 = one (the ordinary form), 2 / 4 / 8 = its split form, in which a
+ * walker is several workgroups of one-pass tiles on several compute units (option "walker_split": 0 never -- the default --, N
+ * always N, -1 eight for batches of <= 32 walkers, where it measures 8 % faster: the reference's default is 50 walkers,
+ * vfit_mcmc.py:127-135).  A row's value is then that of the one-pass tile launches (option "geom" = 1) bit for bit, whatever the
+ * number of groups; it can differ in the last bit from the ordinary form's (two-pass tile sums), which is why it is opt-in. */
 int vp_last_walker_split(const vp_ctx* ctx);
 /* What the far-field expansions of the last lnprob batch covered (first instrument that took any; test / diagnosis hook, it
  * synchronises and copies the masks back): *variant = 0 none, 1 farfield_kernel<6,false> (lines outside clusters and whole

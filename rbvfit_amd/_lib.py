@@ -46,6 +46,7 @@ SIGNATURES = {
     "vp_lnprob_batch_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vp_gather_create": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vp_gather_connect": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
+    "vp_gather_connect_local": (C.c_int, [_ctx, C.POINTER(_ctx), C.c_int]),
     "vp_lnprob_gather_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vp_gather_wait": (C.c_int, [_ctx, C.c_void_p]),
     "vp_gather_state": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),

@@ -93,9 +93,12 @@ struct Tuning {
     int flux_walker = 1;        // vp_model_flux_batch[_device]: batches the walker kernel would take as lnprob batches as ONE launch (0: prep + tile launches)
     int stretch_mailbox = 1;    // vp_stretch_run's overlapped half-steps (stretch_overlap) keep a walker's row, lnprob and version in one 64-byte
                                 // line per buffer where D <= 6 (StretchArgs::ovl = 2); 0 = separate arrays
-    int walker_split = -1;      // walker_kernel's split form (WalkerArgs::split: a walker = several workgroups of one-pass tiles) for batches of at
-                                // most one walker per CU: -1 by batch size (2, 4 or 8 workgroups per walker: the fewest that put a
-                                // workgroup on every CU), 0 never, N > 0 always N (where the form applies at all)
+    int walker_split = 0;       // walker_kernel's split form (WalkerArgs::split: a walker = several workgroups of one-pass tiles): 0 never
+                                // (default), N > 0 always N workgroups per walker where the form applies at all, -1 by batch size (eight
+                                // where W x 8 workgroups leave every CU at most one: W <= 32 on MI355X).  Measured gain: 15.3 -> 14.0 us
+                                // per pass for <= 32 walkers on C1, nothing above (walker_split_for); off by default because it makes a
+                                // row's last bit depend on whether its batch has <= 32 rows (one-pass against two-pass tile sums) --
+                                // a caller who recomputes a chain's lnprob in one large batch would no longer get the chain's bits
     int slice_seg = 0;          // device slice sampler: iterations per segment (the stretch the device works through without the
                                 // host), 0 = as many as the chain chunk and the table of random splits allow (tests: small values)
 };
@@ -243,6 +246,7 @@ struct vp_ctx {
     struct Gather {
         int W = 0, world = 0, rank = 0, seq = 0;
         bool connected = false, finegrained = false;
+        bool local_peers = false;              // the peers' vectors are plain device pointers of contexts of this process (no IPC mapping to close)
         bool shared_device = false;            // some ranks share a GPU: the handshake is a launch of its own (replicas_handshake)
         double* buf = nullptr;                 // (world, W) this rank's gathered vector
         int* flags = nullptr;                  // (MAX_REPLICAS) flags[r] = the last pass whose block from rank r has landed here
@@ -601,8 +605,8 @@ int ctx_num_cus(vp_ctx* c) {
 }
 // walker_kernel's split form (WalkerArgs::split): how many workgroups a walker of a W-row batch gets, 0 = the ordinary form.
 // Where a batch leaves CUs without a workgroup the launch is as long as its heaviest wave's chain (profiles/r05_C1_budget.txt:
-// entry 5.0 + phase-A skeleton 3.0 + line cores 3.3 us of 15.5 at 256 walkers); one-pass tiles halve the chain behind the entry,
-// and several workgroups per walker put them on the idle CUs.  The fewest groups that give every CU a workgroup.
+// entry 5.0 + phase-A skeleton 3.0 + line cores 3.3 us of 15.5 at 256 walkers); one-pass tiles shorten the chain behind the entry,
+// and several workgroups per walker put them on the idle CUs.
 int walker_split_for(vp_ctx* c, int W) {
     if (c->tune.walker_split == 0 || c->inst.size() != 1 || c->tune.walker_clusters || c->gather_rep) return 0;
     const Instrument& in = c->inst[0];
@@ -610,9 +614,14 @@ int walker_split_for(vp_ctx* c, int W) {
     const int nt = in.dev_s.ntiles, ncu = ctx_num_cus(c);
     int G = c->tune.walker_split;
     if (G < 0) {
-        if (ncu <= 0 || W > ncu) return 0;
-        G = 2;
-        while ((long)W * G < ncu && G < 8) G *= 2;
+        // Measured on C1 (us per pass, ordinary form / 2 / 4 / 8 groups; profiles/r05_experiments/split_sweep.txt): 16 walkers 15.25 /
+        // 15.90 / 15.47 / 13.99, 32: 15.29 / 15.88 / 15.51 / 14.05, 50: 15.35 / 15.93 / 15.55 / 15.89, 64: 15.37 / 16.00 / 15.71 / 16.21,
+        // 128: 15.42 / 16.06 / 18.52 / 19.77, 256: 15.42 / 27.99 (two 13-wave workgroups do not fit a CU's wave slots together) --
+        // the form pays only where every group gets a CU's SIMDs to itself (one wave per SIMD): the launch is a 5.5 us entry plus
+        // the heaviest wave's own latency chain (60 % of a lone wave's cycles are s_waitcnt), which one-pass tiles shorten by a
+        // third, not by half.  So: eight groups where W x 8 workgroups still leave every CU at most one, nothing above.
+        if (ncu <= 0 || (long)W * 8 > ncu) return 0;
+        G = 8;
     }
     G = std::min(G, nt);
     if (G < 2 || (long)W * G > 1024) return 0;
@@ -1190,6 +1199,7 @@ static void gather_release(vp_ctx* c) {
     vp_ctx::Gather& g = c->gather;
     for (int r = 0; r < g.world && r < vp::MAX_REPLICAS; ++r) {
         if (r == g.rank) continue;
+        if (g.local_peers) continue;           // (plain pointers into contexts of this process: theirs to free)
         if (g.peer_buf[r]) (void)hipIpcCloseMemHandle(g.peer_buf[r]);
         if (g.peer_flags[r]) (void)hipIpcCloseMemHandle(g.peer_flags[r]);
     }
@@ -1366,16 +1376,21 @@ int vp_add_instrument(vp_ctx* c, int P, const double* wave, const double* flux, 
         // reciprocal of that weight is a per-pixel table (taps in the order the device applies them; a window of NaNs only: NaN).
         bool any_nan = false;
         for (int p = 0; p < P; ++p) any_nan |= wave[p] != wave[p];
-        if (any_nan && lsf_mode == VP_LSF_ASTROPY_EXTEND) {
+        if (any_nan) {
+            // (the other branches -- scipy's convolve1d, no LSF -- get the same instances with a table of 1 and NaN: a NaN sample
+            //  poisons exactly the outputs whose K taps reach it.  Left to the arithmetic it would also poison the outputs the
+            //  ZERO taps of the padded tap groups reach, 0 x NaN being NaN)
             std::vector<double> rbot(P);
             const int halo = d.halo_lo;
             for (int p = 0; p < P; ++p) {
                 double bot = 0.0;
+                bool hit = false;
                 for (int j = 0; j < Kuse; ++j) {
                     const int q = std::min(std::max(p - halo + j, 0), P - 1);
-                    if (wave[q] == wave[q]) bot += kflip[j];
+                    if (wave[q] == wave[q]) bot += kflip[j]; else hit = true;
                 }
-                rbot[p] = bot != 0.0 ? 1.0 / bot : std::nan("");
+                if (lsf_mode == VP_LSF_ASTROPY_EXTEND) rbot[p] = bot != 0.0 ? 1.0 / bot : std::nan("");
+                else rbot[p] = hit ? std::nan("") : 1.0;
             }
             double* d_rbot;
             if ((rc = upload<double>(c, &in, rbot.data(), rbot.size(), &d_rbot))) { for (void* q : in.allocs) hipFree(q); return rc; }
@@ -1609,7 +1624,32 @@ int vp_lnprob_batch_device(vp_ctx* c, int W, int D, const double* d_theta, doubl
 // launch on the stream raises this rank's flag in every peer -- the pass before is complete when it starts -- and its workgroups
 // wait for their peers' flags of that pass before they compute (vp::replicas_handshake): no collective launch, no host
 // involvement, nothing counted at the end of a launch.
-namespace { __global__ void gather_wait_kernel(vp::Replicas R) { vp::replicas_handshake(R); } }
+namespace {
+__global__ void gather_wait_kernel(vp::Replicas R) { vp::replicas_handshake(R); }
+// Ranks that share a GPU (vp_gather_connect's shared_device): a pass is [wait for the peers' flags of the pass before] [the pass's
+// launches] [publish: raise this rank's flag of THIS pass in every peer].  A wait then only ever depends on launches that were
+// enqueued before it -- whatever hardware queue the runtime put them on (several streams of one process can share a queue, and a
+// launch that waits for one queued BEHIND it there would wait for ever; with the flag raised by the next pass's first launch,
+// as ranks on GPUs of their own do it, eight ranks in one process did exactly that).
+__global__ void gather_publish_kernel(vp::Replicas R) {
+    const int lane = threadIdx.x & 63;
+    if (lane < R.n && lane != R.me) __hip_atomic_store(R.flags[lane] + R.me, R.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void gather_waitonly_kernel(vp::Replicas R) {       // until every peer has published pass R.seq - 1
+    const int lane = threadIdx.x & 63, need = R.seq - 1;
+    if (need <= 0 || R.n <= 1) return;
+    for (int spins = 0;; ++spins) {
+        int f = need;
+        if (lane < R.n && lane != R.me) f = __hip_atomic_load(R.flags[R.me] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__ballot(f < need) == 0ull) break;
+        if (spins > vp::SYNC_SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_store(R.timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+}
 
 static vp::Replicas gather_replicas(const vp_ctx* c, int seq) {
     const vp_ctx::Gather& g = c->gather;
@@ -1711,6 +1751,37 @@ int vp_gather_connect(vp_ctx* c, const void* handles_all, int shared_device) {
     return VP_OK;
 }
 
+int vp_gather_connect_local(vp_ctx* c, vp_ctx* const* peers, int shared_device) {
+    if (!c) return VP_EINVAL;
+    CtxGuard g(c);
+    vp_ctx::Gather& G = c->gather;
+    if (!G.buf) return fail(c, VP_ESTATE, "vp_gather_connect_local: call vp_gather_create first");
+    G.shared_device = shared_device != 0;
+    if (G.connected) return VP_OK;
+    if (!peers) return fail(c, VP_EINVAL, "vp_gather_connect_local: NULL peers");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int r = 0; r < G.world; ++r) {
+        if (r == G.rank) continue;
+        const vp_ctx* p = peers[r];
+        // (the peer's gather is read without its lock: the caller sets all ranks up before any of them runs a pass)
+        if (!p || p == c || !p->gather.buf || p->gather.W != G.W || p->gather.world != G.world || p->gather.rank != r)
+            return fail(c, VP_EINVAL, "vp_gather_connect_local: peers[" + std::to_string(r) + "] has no gather of this shape with rank " + std::to_string(r));
+        if (p->device != c->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, c->device, p->device) != hipSuccess || !can)
+                return fail(c, VP_EHIP, "vp_gather_connect_local: device " + std::to_string(c->device) + " cannot map device " + std::to_string(p->device));
+            hipError_t e = hipDeviceEnablePeerAccess(p->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(c, VP_EHIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+        G.peer_buf[r] = p->gather.buf;
+        G.peer_flags[r] = p->gather.flags;
+    }
+    G.local_peers = true;
+    G.connected = true;
+    return VP_OK;
+}
+
 int vp_lnprob_gather_device(vp_ctx* c, int W, int D, const double* d_theta, void* hip_stream) {
     if (!c) return VP_EINVAL;
     CtxGuard g(c);
@@ -1724,13 +1795,18 @@ int vp_lnprob_gather_device(vp_ctx* c, int W, int D, const double* d_theta, void
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if ((rc = foreign_stream_fence(c, s))) return rc;
     vp::Replicas R = gather_replicas(c, ++G.seq);
-    if (G.shared_device && G.world > 1) {            // the handshake as a one-wave launch in front of the pass
-        hipLaunchKernelGGL(gather_wait_kernel, dim3(1), dim3(64), 0, s, R);
+    const bool shared = G.shared_device && G.world > 1;
+    if (shared) {                                    // ranks that share a GPU: wait in front, publish behind (gather_publish_kernel)
+        hipLaunchKernelGGL(gather_waitonly_kernel, dim3(1), dim3(64), 0, s, R);
         R.sync = 0;
     }
     c->gather_rep = &R;
     rc = enqueue_lnprob(c, W, d_theta, nullptr, s);
     c->gather_rep = nullptr;
+    if (shared && rc == VP_OK) {
+        hipLaunchKernelGGL(gather_publish_kernel, dim3(1), dim3(64), 0, s, gather_replicas(c, G.seq));
+        HIP_TRY(c, hipGetLastError());
+    }
     return rc;
 }
 
@@ -1741,7 +1817,8 @@ int vp_gather_wait(vp_ctx* c, void* hip_stream) {
     if (!G.connected) return fail(c, VP_ESTATE, "vp_gather_wait: no connected gather");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    hipLaunchKernelGGL(gather_wait_kernel, dim3(1), dim3(64), 0, s, gather_replicas(c, G.seq + 1));
+    if (G.shared_device && G.world > 1) hipLaunchKernelGGL(gather_waitonly_kernel, dim3(1), dim3(64), 0, s, gather_replicas(c, G.seq + 1));
+    else hipLaunchKernelGGL(gather_wait_kernel, dim3(1), dim3(64), 0, s, gather_replicas(c, G.seq + 1));
     HIP_TRY(c, hipGetLastError());
     return VP_OK;
 }

@@ -47,7 +47,9 @@ enum { ABL_NOFAR = 1,       // no evaluation in the |x| >= 30 tiers (x and the t
        ABL_ENTRY = 64,      // walker_kernel ends behind its first barrier: what the entry costs alone
        ABL_NOSMALLEXP = 128,  // no short Taylor form of exp where a chunk is shallow
        ABL_NOPRIO = 256,      // no raised issue priority for waves with line cores
-       ABL_EMPTY = 512 };     // walker_kernel returns at once: what a launch of this shape costs
+       ABL_EMPTY = 512,       // walker_kernel returns at once: what a launch of this shape costs
+       ABL_NOFFPOLY = 1024,   // the blocks' far-field polynomials are not evaluated (FF instance)
+       ABL_NOMP = 2048 };     // no multipole evaluation of far clusters (their members are skipped all the same)
 #define VP_ABL(bit) ((VP_DIAG & (bit)) != 0)
 
 struct LinesDev {          // static per-instrument line tables (CompiledModelData, voigt_model.py:265-280)
@@ -1276,6 +1278,11 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                         const bool far0 = __ballot(!(ym >= y0)) == 0ull;      // every lane far enough (NaN counts as near)
                         const bool far1 = VP_NONE_BELOW(ym, y1), far2 = VP_NONE_BELOW(ym, y2), far3 = VP_NONE_BELOW(ym, y3),
                                    far4 = VP_NONE_BELOW(ym, y4);
+                        if (far0 && VP_ABL(ABL_NOMP)) {
+                            l = max(l, nxt.cl_end - 1);
+                            nxt = load_eager<SOLO>(lcw + (size_t)min(VP_NEXT_LINE(l + 1), I.L - 1) * LC_STRIDE);
+                            continue;
+                        }
                         if (far0) {
                             if (far2) {
                                 if (far3) {
@@ -1350,7 +1357,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                 }
             }
 #undef VP_NEXT_LINE
-            if (FF) {      // all the far lines of this block at once: FF_NC FMAs per pixel
+            if (FF && !VP_ABL(ABL_NOFFPOLY)) {      // all the far lines of this block at once: FF_NC FMAs per pixel
                 rec_t tb = as_rec(VP_LATE_FIELD(W1, I, ff_tab)) + 4 * fblk;
                 const double ihw = tb[2], gci = tb[3];
                 double t[RB], pa[RB];
@@ -1502,7 +1509,11 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     }
     if (OUT != 2) {
         for (int ob = 0; ob < nout; ob += LSF_PX * TILE_THREADS)
+#ifdef VP_EXP_TILE_EARLY
+            lsf_block6<OUT, SOLO || W1, W1, NANFIX>(I, fl, VP_ABL(ABL_NOLSF) ? 0 : Kp, ob, nout, p0, w, tid, out, out_stride, acc);
+#else
             lsf_block6<OUT, SOLO, W1, NANFIX>(I, fl, VP_ABL(ABL_NOLSF) ? 0 : Kp, ob, nout, p0, w, tid, out, out_stride, acc);
+#endif
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }

@@ -182,6 +182,13 @@ class Engine:
         buf = C.create_string_buffer(bytes(handles_all), len(handles_all))
         self._check(self._lib.vp_gather_connect(self._ctx, C.cast(buf, C.c_void_p), int(bool(shared_device))))
 
+    def gather_connect_local(self, peers, shared_device: bool = True):
+        """``gather_connect`` for ranks that are ``Engine`` objects of THIS process (``vp_gather_connect_local``): ``peers`` =
+        the ranks' engines in rank order (this one's own entry is ignored)."""
+        self._guard()
+        arr = (C.c_void_p * len(peers))(*[p._ctx.value for p in peers])
+        self._check(self._lib.vp_gather_connect_local(self._ctx, arr, int(bool(shared_device))))
+
     @property
     def device_identity(self) -> str:
         """Host name and PCI bus id of the context's GPU: what tells ranks apart that share a device."""

@@ -294,39 +294,47 @@ def test_walker_kernel_split_form_small_batches():
         tiles = e.lnprob(th)
         assert e.last_launch_kind == "tiles"
         e.set_option("walker", -1); e.set_option("geom", -1); e.set_option("finalize", -1)
-        want_groups = {256: 2, 200: 2, 128: 2, 100: 4, 64: 4, 50: 8, 32: 8, 7: 8, 1: 8}
-        for W, G in want_groups.items():
+        for W in (256, 32, 1):                              # off by default: a row's bits do not depend on the size of its batch
+            e.lnprob(th[:W])
+            assert e.last_launch_kind == "walker" and e.last_walker_split == 0
+        e.set_option("walker_split", -1)
+        ncu = 256                                           # MI355X
+        for W in (256, 128, 64, 33, 32, 17, 7, 1):          # "by batch size": eight groups while W x 8 workgroups leave a CU at most one
             got = e.lnprob(th[:W])
+            G = 8 if W * 8 <= ncu else 0
             assert e.last_launch_kind == "walker" and e.last_walker_split == G, (W, e.last_launch_kind, e.last_walker_split)
-            assert np.array_equal(got, tiles[:W], equal_nan=True), W
+            if G:
+                assert np.array_equal(got, tiles[:W], equal_nan=True), W
         assert np.isneginf(tiles[5]) and np.isneginf(tiles[250]) and np.isnan(tiles[9])
         rows = [0, 1, 5, 9, 17, 100, 255]
         ref = vo.lnprob_batch(th[rows], wl.lb, wl.ub, insts)
         fin = np.isfinite(ref)
         np.testing.assert_allclose(tiles[rows][fin], ref[fin], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
-        for G in (2, 4, 8, 0):
-            e.set_option("walker_split", G)
-            got = e.lnprob(th)
-            assert e.last_walker_split == G
-            if G:
-                assert np.array_equal(got, tiles, equal_nan=True)
-            else:                                          # the ordinary form sums two-pass tiles: the last bit may differ
-                ok = np.isfinite(tiles)
-                np.testing.assert_allclose(got[ok], tiles[ok], rtol=4e-16, atol=0)
-        e.set_option("walker_split", -1)
+        for W, groups in ((256, (2, 4, 0)), (128, (2, 4, 8, 0)), (12, (2, 4, 8, 0))):      # forced: any number of groups, same bits
+            for G in groups:
+                e.set_option("walker_split", G)
+                got = e.lnprob(th[:W])
+                assert e.last_walker_split == G
+                if G:
+                    assert np.array_equal(got, tiles[:W], equal_nan=True)
+                else:                                      # the ordinary form sums two-pass tiles: the last bit may differ
+                    ok = np.isfinite(tiles[:W])
+                    np.testing.assert_allclose(got[ok], tiles[:W][ok], rtol=4e-16, atol=0)
+        e.set_option("walker_split", 8)
         e.set_option("prearm", 1)                           # the split form behind a pushed-to launch
         for _ in range(4):
             assert np.array_equal(e.lnprob(th[:64]), tiles[:64], equal_nan=True)
-        assert e.prearm_counts["used"] >= 2
+        assert e.prearm_counts["used"] >= 2 and e.last_walker_split == 8
         e.set_option("prearm", -1)
-        # 257 walkers: more than one per CU -- the ordinary form
-        big = np.concatenate([th, th[:1]])
-        e.lnprob(big)
-        assert e.last_launch_kind == "walker" and e.last_walker_split == 0
+        e.set_option("walker_split", -1)
         # the device-resident stretch move on the split form: chain identical to the host loop's replay of the same draws is
         # covered in test_gpu_sampler (half-ensembles of <= 256 walkers take it by themselves); here: it runs and moves
-        pos, lp, *_ = e.stretch_run(wl.thetas[:64], 20, seed=5, store_chain=False)
-        np.testing.assert_array_equal(lp, e.lnprob(pos))
+        for W in (64, 48):                                  # half-ensembles of 32 / 24 walkers: the split form, with and without overlap
+            pos, lp, *_ = e.stretch_run(wl.thetas[:W], 20, seed=5, store_chain=False)
+            half = e.lnprob(pos[:W // 2])
+            assert e.last_walker_split == 8
+            np.testing.assert_array_equal(lp[:W // 2], half)
+        e.set_option("walker_split", 0)
     finally:
         wl.engine.close()
 

@@ -92,7 +92,7 @@ def test_random_configuration(seed):
             r = e.lnprob(thetas)
             if e.last_launch_kind == "walker" and e.last_walker_split > 0:
                 got_split[G] = (r, e.last_walker_split)
-        e.set_option("walker_split", -1)
+        e.set_option("walker_split", 0)
         e.set_option("walker", 0); e.set_option("geom", 1); e.set_option("finalize", 0)
         got_small = e.lnprob(thetas)                                   # the one-pass tile launches: the split form's geometry
         for k in ("walker", "geom", "finalize"):

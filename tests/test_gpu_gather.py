@@ -118,26 +118,76 @@ def _rank(rank, world, port, q, config="C1", inkernel=False):
     q.put((rank, out))
 
 
+@pytest.mark.parametrize("world,config", [(8, "C1"), (5, "C1"), (8, "C2")])
+def test_eight_ranks_in_one_process_gather_into_each_other(world, config):
+    """The exchange at the size of the node the scaling bench runs on: 8 ranks -- 8 flags per vector, 8
+    blocks, the handshake raising 7 peers' flags -- as 8 contexts of THIS process on device 0 (the GPU boxes allow six processes
+    on a card, and a process cannot open its own IPC handles: vp_gather_connect_local takes the peers' device pointers
+    instead).  Every rank evaluates its own block of 64 walkers with launches on its own stream; after 30 back-to-back passes,
+    each waiting on the device for all peers' blocks of the pass before, every rank's gathered vector holds all 8 blocks bit
+    for bit.  C1: one launch per pass (walker_kernel writes into the vectors); C2: several (the finalize launch does)."""
+    torch = pytest.importorskip("torch")
+    from rbvfit_amd.workloads import make_workload
+    W = 64 if config == "C1" else 24
+    wls = [make_workload(config, walkers=W, walker_seed=1 + r) for r in range(world)]
+    engs = [w.engine for w in wls]
+    try:
+        for r, e in enumerate(engs):
+            e.gather_create(W, world, r)
+        for e in engs:
+            e.gather_connect_local(engs, shared_device=True)          # ranks share the GPU: the handshake is a launch of its own
+        streams = [torch.cuda.Stream() for _ in engs]
+        thetas = [torch.from_numpy(w.thetas).cuda() for w in wls]
+        torch.cuda.synchronize()
+        for k in range(30):
+            for r, e in enumerate(engs):
+                e.lnprob_gather_device(thetas[r].data_ptr(), W, streams[r].cuda_stream)
+        for r, e in enumerate(engs):
+            e.gather_wait(streams[r].cuda_stream)
+        torch.cuda.synchronize()
+        local = [e.lnprob(w.thetas) for e, w in zip(engs, wls)]
+        want = np.concatenate(local)
+        assert len({a.tobytes() for a in local}) == world              # every rank its own walkers
+        for r, e in enumerate(engs):
+            ptr, timed_out = e.gather_state()
+            assert not timed_out
+            from rbvfit_amd.dist import _DevicePointer
+            got = torch.as_tensor(_DevicePointer(ptr, W * world), device="cuda").cpu().numpy()
+            np.testing.assert_array_equal(got, want)
+        with pytest.raises(RuntimeError, match="peers"):
+            fresh = make_workload("C1", walkers=W)
+            try:
+                fresh.engine.gather_create(W, world, 0)
+                fresh.engine.gather_connect_local([fresh.engine] + engs[1:-1] + [fresh.engine], shared_device=True)   # last entry: not rank world-1
+            finally:
+                fresh.engine.close()
+    finally:
+        for e in engs:
+            e.gather_destroy()
+        for e in engs:
+            e.close()
+
+
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("config,inkernel", [("C1", False), ("C1", True), ("C2", False), ("C2", True)])
-def test_two_processes_on_one_gpu_gather_into_each_other(config, inkernel):
+@pytest.mark.parametrize("config,inkernel,world", [("C1", False, 2), ("C1", True, 2), ("C2", False, 2), ("C2", True, 2), ("C1", False, 4)])
+def test_two_processes_on_one_gpu_gather_into_each_other(config, inkernel, world):
     """config: one launch per pass / several; inkernel: the handshake inside the pass's first launch (what ranks on GPUs of their
     own get) or -- ranks that share a GPU are told apart by their device identity -- a one-wave launch in front of it."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + 777 + (13 if config == "C2" else 0) + (29 if inkernel else 0)) % 2000
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q, config, inkernel)) for r in range(2)]
+    port = 29500 + (os.getpid() + 777 + (13 if config == "C2" else 0) + (29 if inkernel else 0) + 41 * world) % 2000
+    procs = [ctx.Process(target=_rank, args=(r, world, port, q, config, inkernel)) for r in range(world)]      # (with this process: <= 6 on the card)
     for p in procs:
         p.start()
     res = dict(q.get(timeout=500) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res[0]["reason"] == "" and res[1]["reason"] == "", (res[0]["reason"], res[1]["reason"])
-    for r in (0, 1):
+    assert all(res[r]["reason"] == "" for r in range(world)), [res[r]["reason"] for r in range(world)]
+    want = np.concatenate([res[r]["local"] for r in range(world)])
+    for r in range(world):
         assert res[r]["shared"] == (not inkernel)
         assert not res[r]["timed_out"]
-        want = np.concatenate([res[0]["local"], res[1]["local"]])
-        np.testing.assert_array_equal(res[r]["gathered"], want)    # every rank holds both blocks, bit for bit
+        np.testing.assert_array_equal(res[r]["gathered"], want)    # every rank holds all blocks, bit for bit
     assert not np.array_equal(res[0]["local"], res[1]["local"])

@@ -516,6 +516,34 @@ def test_sharded_ensemble_reproduces_the_single_context_chain(walker, sync):
                 m.stretch_run(p0[:49], 2, seed=1)
 
 
+@pytest.mark.parametrize("walker,sync", [(1, 0), (0, 0), (1, 1)])
+def test_ensemble_sharded_over_eight_contexts(walker, sync):
+    """The same at the size of the node the scaling bench runs on: device 0 listed EIGHT times -- 25 rows per
+    half-step in blocks of 4, 4, 4, 4, 4, 4, 1 and 0 (a context without rows still takes part in every barrier), eight replicas
+    written through eight sets of pointers, eight flags / events per half-step -- and the slice sampler's rounds cut eight ways.
+    Chains, lnprob, acceptance counts, mu history and evaluation counts of the single-context runs, bit for bit."""
+    wl = _workload(W=50, pixels=700)
+    eng, p0 = wl.engine, wl.thetas
+    eng.set_option("walker", walker)
+    ref = eng.stretch_run(p0, 16, seed=5)
+    with _multi_for(wl, [0] * 8) as m:
+        assert m.n_devices == 8
+        m.set_option("walker", walker)
+        m.set_option("multi_sync", sync)
+        got = m.stretch_run(p0, 16, seed=5)
+        for a, b in zip(ref, got):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(m.lnprob(p0), eng.lnprob(p0))          # 50 rows in blocks of 7, 7, ..., 1
+        np.testing.assert_array_equal(m.lnprob(p0[:5]), eng.lnprob(p0[:5]))  # fewer rows than contexts
+        if sync == 0:
+            sref = eng.slice_run(p0, 6, seed=9)
+            sgot = m.slice_run(p0, 6, seed=9)
+            for k in ("pos", "lnprob", "chain", "chain_lnprob", "mu_history"):
+                np.testing.assert_array_equal(sref[k], sgot[k], err_msg=k)
+            assert (sref["mu"], sref["tune_state"], sref["n_evals"]) == (sgot["mu"], sgot["tune_state"], sgot["n_evals"])
+    wl.engine.close()
+
+
 @pytest.mark.parametrize("walker", [1, 0])
 def test_sharded_slice_sampler_reproduces_the_single_context_chain(walker):
     """vp_multi_slice_run: replicated sampler state, every round's lnprob batch cut into one block of trial rows per
