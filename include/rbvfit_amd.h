@@ -101,10 +101,13 @@ int vp_update_spectrum(vp_ctx* ctx, int inst, const double* flux, const double* 
  * returns as soon as every output row has arrived there (the rows are pre-set to a NaN bit pattern that no arithmetic produces and
  * each is written exactly once; inputs carrying that payload make the call wait on a stream-written completion word instead):
  * `out` is complete when it returns, as with any synchronous call.
- * Pre-armed launches (option "prearm": -1 default, 0 never, 1 always; "prearm_us", default 1000): for batches that are one
+ * Pre-armed launches (option "prearm": -1 default, 0 never, 1 always; "prearm_us", default 500): for batches that are one
  * walker_kernel launch, a call of the previous call's shape that came within prearm_us / 2 of its return leaves the launch for the NEXT batch
- * of this shape on the GPU.  It has done everything that does not depend on theta and waits -- at most prearm_us microseconds,
- * holding its compute units -- for the host to push that batch: the next call then costs no launch and no read over PCIe: it writes
+ * of this shape on the GPU.  It has done everything that does not depend on theta and waits, holding its compute units, for the
+ * host to push that batch -- no longer than the caller's own rhythm suggests: 1.5 x the recent gap between its calls + 10 us (at
+ * least 20 us, at most prearm_us; "prearm" = 1 waits the whole prearm_us), and a caller whose launches expire unused is not
+ * pre-armed for again for 8, 16, ... calls.  Work that anything else puts on the GPU meanwhile (another library of the process,
+ * another process) waits that long at most.  The next call then costs no launch and no read over PCIe: it writes
  * theta and a go word into the launch's slots in device memory through the PCIe BAR (GPUs without a large BAR: no pre-armed launches) and
  * waits for the rows.  Every other entry point of the context, every call on another context of this process on the same
  * GPU, vp_ctx_destroy and process exit send a waiting launch away first; a launch that expired, or a batch of another shape, falls back to the ordinary launch.  Results do not

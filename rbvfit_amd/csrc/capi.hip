@@ -89,7 +89,8 @@ struct Tuning {
                                 // command-processor latency, no read over PCIe and none of the kernel's theta-independent entry between the
                                 // caller's theta and the arithmetic.  -1: when the previous call came within prearm_us / 2 of the
                                 // one before returning (a sampler's loop), 0 never, 1 after every eligible call
-    int prearm_us = 1000;       // how long a pre-armed launch waits for its batch before it leaves (the GPU is held meanwhile)
+    int prearm_us = 500;        // the LONGEST a pre-armed launch waits for its batch before it leaves (the GPU is held meanwhile); the wait it is
+                                // actually given follows the caller's rhythm (vp_ctx::Prearm::gap_ema_us): 1.5 x the recent gap between calls + 10 us
     int flux_walker = 1;        // vp_model_flux_batch[_device]: batches the walker kernel would take as lnprob batches as ONE launch (0: prep + tile launches)
     int stretch_mailbox = 1;    // vp_stretch_run's overlapped half-steps (stretch_overlap) keep a walker's row, lnprob and version in one 64-byte
                                 // line per buffer where D <= 6 (StretchArgs::ovl = 2); 0 = separate arrays
@@ -239,6 +240,14 @@ struct vp_ctx {
         int last_W = -1;              // rows of the previous vp_lnprob_batch call
         std::chrono::steady_clock::time_point last_return;
         int misses = 0;               // consecutive launches that expired although their batch had been pushed
+        // being a good neighbour: a waiting launch holds every CU, and only this library's own entry points can send it away --
+        // anything else the process (or another process) puts on the GPU waits it out.  So it waits no longer than the caller's
+        // own rhythm suggests, and a caller whose launches expire unused is left alone for a while.
+        double gap_ema_us = 0.0;      // running mean of the time between a call's return and the next call (calls that came within prearm_us)
+        int budget_us = 0;            // how long the launch now waiting was told to wait
+        int cooldown = 0;             // calls still to pass before the next launch is pre-armed (set when one expired unused)
+        int cooldown_next = 8;        // ... and what the next unused expiry will set it to (doubles, back to 8 after 16 used in a row)
+        int used_streak = 0;
         int64_t used = 0, expired = 0, cancelled = 0;     // (vp_prearm_counts)
     } arm;
     bool sentinel_unsafe = false;    // some static input (bounds, spectra, line tables, taps) carries the sentinel's NaN payload
@@ -724,8 +733,12 @@ void launch_walker(vp_ctx* c, int W, const double* d_theta, double* d_out, hipSt
         a.arm_slot_doubles = c->arm.slot_doubles;
         a.arm_host = c->arm.h_dev;
         a.arm_seq = c->arm.seq;
-        a.arm_ticks = 100 * std::min(std::max(1, c->tune.prearm_us), 100000);      // (100 MHz clock; at most 100 ms: far below the
-                                                                                   //  other waves' own bound of ~1 s of polling, SYNC_SPIN_LIMIT)
+        // (100 MHz clock.  The caller's own rhythm: one and a half times its recent gap between calls + 10 us, at least 20 us, at most prearm_us --
+        //  itself at most 100 ms, far below the other waves' own bound of ~1 s of polling, SYNC_SPIN_LIMIT.  "prearm" = 1 -- tests,
+        //  experiments -- waits the whole prearm_us.)
+        const int cap = std::min(std::max(1, c->tune.prearm_us), 100000);
+        c->arm.budget_us = c->tune.prearm > 0 ? cap : std::min(cap, std::max(20, (int)(1.5 * c->arm.gap_ema_us) + 10));
+        a.arm_ticks = 100 * c->arm.budget_us;
     }
     vp::StretchArgs st{};
     if (gather) st.rep = *gather;            // (the plain form's only use of the sampler arguments: where the results go)
@@ -1859,7 +1872,13 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta, int a
             __atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) != c->arm.seq)
             use_armed = true;
         else {
-            if (__atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) == c->arm.seq) { c->arm.live = false; ++c->arm.expired; }
+            if (__atomic_load_n(&c->arm.h[vp::ARM_EXPIRED_WORD], __ATOMIC_ACQUIRE) == c->arm.seq) {
+                // it waited its whole budget for nothing -- the GPU was held for nobody: leave this caller alone for a while
+                c->arm.live = false; ++c->arm.expired;
+                c->arm.cooldown = c->arm.cooldown_next;
+                c->arm.cooldown_next = std::min(4096, 2 * c->arm.cooldown_next);
+                c->arm.used_streak = 0;
+            }
             prearm_cancel(c);
         }
     }
@@ -1896,6 +1915,7 @@ static int lnprob_host_begin(vp_ctx* c, int W, int D, const double* theta, int a
             c->arm.cur = c->arm.live_stream;
             c->arm.seq_inflight = c->arm.seq;
             ++c->arm.used;
+            if (++c->arm.used_streak >= 16) c->arm.cooldown_next = 8;
             c->last_kind = 1;
             c->last_ff = vp_ctx::LastFF{};
         } else {
@@ -2033,8 +2053,16 @@ int vp_lnprob_batch(vp_ctx* c, int W, int D, const double* theta, double* out) {
     // pre-arm the next call's launch?  (prearm = -1: when this call came quickly behind the last one's return -- a sampler's loop)
     int arm_next = 0;
     if (c->tune.prearm > 0) arm_next = 1;
-    else if (c->tune.prearm < 0 && c->arm.have_last && c->arm.last_W == W)      // (ragged batches -- a slice sampler's rounds -- never arm)
-        arm_next = std::chrono::steady_clock::now() - c->arm.last_return < std::chrono::microseconds(std::max(1, c->tune.prearm_us / 2)) ? 1 : 0;
+    else if (c->tune.prearm < 0 && c->arm.have_last && c->arm.last_W == W) {    // (ragged batches -- a slice sampler's rounds -- never arm)
+        const double gap = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c->arm.last_return).count();
+        if (gap < 0.5 * std::max(1, c->tune.prearm_us)) {
+            c->arm.gap_ema_us = c->arm.gap_ema_us > 0.0 ? 0.75 * c->arm.gap_ema_us + 0.25 * gap : gap;
+            arm_next = 1;
+        } else {
+            c->arm.gap_ema_us = 0.0;             // a pause: the rhythm starts again
+        }
+        if (arm_next && c->arm.cooldown > 0) { --c->arm.cooldown; arm_next = 0; }
+    }
     c->arm.last_W = W;
     if ((rc = lnprob_host_begin(c, W, D, theta, arm_next))) return rc;
     rc = lnprob_host_end(c, W, D, out);

@@ -560,6 +560,8 @@ def test_integration_md_binding_stub_runs_as_written():
         "G": {"model": Compiled(data).model_flux, "wave": g("wave"), "flux": g("flux"),
               "inv_sigma2": g("inv_sigma2"), "log_inv_sigma2": g("log_inv_sigma2")}})
     post = ns["AmdPosterior"](fitter)
+    quiet = ns["AmdPosterior"](fitter, prearm=0)             # the constructor argument a shared-GPU deployment passes
+    np.testing.assert_array_equal(quiet(z["thetas"]), post(z["thetas"]))
     got = post(z["thetas"])
     fin = np.isfinite(z["lnprob"])
     np.testing.assert_allclose(got[fin], z["lnprob"][fin], rtol=LNPROB_RTOL, atol=LNPROB_ATOL)
