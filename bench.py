@@ -714,6 +714,22 @@ def rank_main(args):
                     dts = time.perf_counter() - ts0
                     slice_info = dict(steps_per_sec=nsl / dts, lnprob_evals_per_walker_step=r1["n_evals"] / (nsl * W),
                                       evals_per_sec=r1["n_evals"] / dts, mu=r1["mu"])
+                    if args.config in ("C0", "C1"):
+                        # BASELINE config 4 names zeus walkers on the joint two-instrument fit: the same sampler on C3 at its
+                        # whole ensemble of 2048 walkers (one GPU), a few iterations
+                        try:
+                            from rbvfit_amd.workloads import make_workload as _mk
+                            w3 = _mk("C3", walkers=2048)
+                            q0 = w3.engine.slice_run(w3.thetas, 2, seed=1, store_chain=False)
+                            ts0 = time.perf_counter()
+                            q1 = w3.engine.slice_run(q0["pos"], 6, lnprob=q0["lnprob"], seed=1, step0=2, mu=q0["mu"], tune=q0["tune"],
+                                                     store_chain=False)
+                            dt3 = time.perf_counter() - ts0
+                            slice_info["c3_2048_walkers"] = dict(steps_per_sec=6 / dt3, lnprob_evals_per_walker_step=q1["n_evals"] / (6 * 2048),
+                                                                 evals_per_sec=q1["n_evals"] / dt3)
+                            w3.engine.close()
+                        except Exception as exc:                   # (an extra: never fails the line)
+                            slice_info["c3_2048_walkers"] = {"error": str(exc)}
 
         spread_info = multi_info = None
         if not args.no_extras and W % 2 == 0 and args.spread == "ball":

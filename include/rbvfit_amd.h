@@ -160,6 +160,12 @@ int vp_gather_destroy(vp_ctx* ctx);
  * either way). */
 int vp_model_flux_batch(vp_ctx* ctx, int inst, int W, int D, const double* theta, double* out,
                         int convolved);
+/* out[w] = c0 - sum_p weights[p] * model_flux(theta_w)[p]  for a batch: the model rows never leave the GPU, W doubles come back.
+ * Replaces the equivalent-width integral of the curve-of-growth grid, np.trapz(1 - flux, x=wave) per (N, b) pair
+ * (compute_cog.py:56-60, 75-86): weights = the trapezoid weights of the wavelength grid, c0 = their sum (rbvfit_amd.cog).
+ * weights (P) and out (W) are host memory. */
+int vp_model_flux_rowsum(vp_ctx* ctx, int inst, int W, int D, const double* theta, const double* weights, double c0,
+                         int convolved, double* out);
 int vp_model_flux_batch_device(vp_ctx* ctx, int inst, int W, int D, const double* d_theta,
                                double* d_out, int convolved, void* hip_stream);
 

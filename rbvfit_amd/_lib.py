@@ -52,6 +52,7 @@ SIGNATURES = {
     "vp_gather_state": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "vp_gather_destroy": (C.c_int, [_ctx]),
     "vp_model_flux_batch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int]),
+    "vp_model_flux_rowsum": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, _dp]),
     "vp_model_flux_batch_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]),
     "vp_model_flux_components": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _dp, _dp]),

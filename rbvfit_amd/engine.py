@@ -259,6 +259,18 @@ class Engine:
                                                   _dp(out), 1 if convolved else 0))
         return out
 
+    def model_flux_rowsum(self, inst: int, theta, weights, c0: float = 0.0, convolved: bool = True) -> np.ndarray:
+        """(W,): c0 - sum_p weights[p] * model_flux(theta_w)[p], reduced on the GPU (``vp_model_flux_rowsum``): the rows stay in HBM."""
+        self._guard()
+        th = self._theta2d(theta)
+        wts = _f64(weights).ravel()
+        if wts.size != self.n_pixels[inst]:
+            raise ValueError("weights must have one entry per pixel of the instrument")
+        out = np.empty(th.shape[0], dtype=np.float64)
+        self._check(self._lib.vp_model_flux_rowsum(self._ctx, int(inst), th.shape[0], th.shape[1], _dp(th), _dp(wts), float(c0),
+                                                   1 if convolved else 0, _dp(out)))
+        return out
+
     def model_flux_device(self, inst: int, d_theta_ptr: int, d_out_ptr: int, W: int, convolved=True, stream_ptr=0):
         self._guard()
         self._check(self._lib.vp_model_flux_batch_device(self._ctx, int(inst), int(W), self.ndim,

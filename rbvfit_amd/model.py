@@ -299,6 +299,19 @@ class CompiledVoigtModel:
     def __call__(self, theta, wavelength):
         return self.model_flux(theta, wavelength)
 
+    def equivalent_width(self, theta, wavelength) -> np.ndarray:
+        """``np.trapz(1 - model_flux(theta, wavelength), x=wavelength)`` per theta row (compute_cog.py:56-60) with the integral
+        formed on the GPU: (W,) doubles come back instead of (W, P) rows.  Trapezoid weights c_i = (x_{i+1} - x_{i-1}) / 2
+        (half intervals at the ends): EW = sum c_i - sum c_i flux_i."""
+        theta = np.asarray(theta, dtype=np.float64)
+        x = np.asarray(wavelength, dtype=np.float64)
+        c = np.zeros_like(x)
+        d = np.diff(x)
+        c[:-1] += 0.5 * d
+        c[1:] += 0.5 * d
+        out = self._engine_for(x).model_flux_rowsum(0, theta, c, c0=float(np.sum(c)))
+        return float(out[0]) if theta.ndim == 1 else out
+
     def components(self, theta, wavelength) -> np.ndarray:
         """Per-line unconvolved flux exp(-tau_l): (L, P) for one theta, (W, L, P) for a batch
         (``_evaluate_compiled_model(..., return_components=True)['components']``, voigt_model.py:232-238)."""

@@ -490,6 +490,14 @@ def test_curve_of_growth_grid_is_one_batch():
             fl = vo.model_flux(d, np.array([Nlist[i], blist[j], 0.0]), cog.wave)
             assert abs(cog.Wlist[i, j] - trap(1 - fl, x=cog.wave)) < 1e-11
     assert np.all(np.diff(cog.Wlist, axis=0) > 0)            # EW grows with N
+    # the integral is a reduction on the device behind the model launch (vp_model_flux_rowsum): against the host's trapezoid
+    # over the engine's own rows
+    NN, BB = np.meshgrid(np.asarray(Nlist), np.asarray(blist), indexing="ij")
+    theta = np.stack([NN.ravel(), BB.ravel(), np.zeros(NN.size)], axis=1)
+    rows = cog.model_compiled.model_flux(theta, cog.wave)
+    np.testing.assert_allclose(cog.Wlist.ravel(), trap(1.0 - rows, x=cog.wave, axis=1), rtol=0, atol=2e-13)
+    assert isinstance(cog.model_compiled.equivalent_width(theta[5], cog.wave), float)
+    cog.model_compiled.close()
 
 
 @pytest.mark.parametrize("K", [65, 301, 1025, 2049])
