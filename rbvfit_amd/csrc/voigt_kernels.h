@@ -894,6 +894,9 @@ __device__ __forceinline__ void wing_rb(const double (&x)[RB], KP K, double (&ta
     double s[RB], acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) s[r] = fast_rcp1(x[r] * x[r]);
+    // (one reciprocal for the pass's three chunks -- 1 / (x0^2 x1^2 x2^2), then products; v_rcp_f64 issues at a quarter of the FMA
+    //  rate -- measured 1 % faster unguarded, but a NaN wavelength sample would then poison its lane's other two pixels, and
+    //  both guards that keep it in its own pixel cost more than the trick saves: profiles/r05_experiments/ab3..ab5)
     const double kt = K[M - 1];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = kt;
@@ -1187,7 +1190,8 @@ __device__ __forceinline__ int next_near_line(unsigned long long nearm, int from
 //   fl[span + FL_PAD] tau -> flux (+ zeros) | red[4] | Dawson table | exp table | per-chunk "line core" masks
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
 // fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
-template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false, bool FF = false, bool W1 = false, bool NANFIX = false>
+template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false, bool FF = false, bool W1 = false, bool NANFIX = false,
+          bool MP = true>      // MP = false: the records hold no multipole clusters (walker_kernel's plain instances): the path is not compiled
 __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
                                             int tid, int nthreads, const TilePre& pre, bool first,
                                             double* __restrict__ out, int out_stride VP_STAMP_ARG, bool daw_ready = false,
@@ -1261,8 +1265,8 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
                 for (int l = lfirst; l < l1; l = VP_NEXT_LINE(l + 1)) {
                     // far from a whole cluster of components?  one multipole evaluation replaces all of
                     // its member lines (only tried at the first line of a cluster that fits this block)
-                    const int mp = (I.line_sel < 0) ? nxt.mp : -1;
-                    if (mp >= 0 && nxt.cl_end <= l1) {
+                    const int mp = (MP && I.line_sel < 0) ? nxt.mp : -1;
+                    if (MP && mp >= 0 && nxt.cl_end <= l1) {
                         rec_t mrec = lcw + (size_t)(I.L + mp) * LC_STRIDE;
                         // A, B and the four tier radii arrive with ONE scalar load (no load behind a tier decision
                         // except the Q_j themselves)
@@ -1509,11 +1513,7 @@ __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double*
     }
     if (OUT != 2) {
         for (int ob = 0; ob < nout; ob += LSF_PX * TILE_THREADS)
-#ifdef VP_EXP_TILE_EARLY
-            lsf_block6<OUT, SOLO || W1, W1, NANFIX>(I, fl, VP_ABL(ABL_NOLSF) ? 0 : Kp, ob, nout, p0, w, tid, out, out_stride, acc);
-#else
             lsf_block6<OUT, SOLO, W1, NANFIX>(I, fl, VP_ABL(ABL_NOLSF) ? 0 : Kp, ob, nout, p0, w, tid, out, out_stride, acc);
-#endif
     } else {
         for (int ib = tid; ib < nout; ib += TILE_THREADS) out[(size_t)w * out_stride + p0 + ib] = fl[ib + I.halo_lo];
     }
@@ -2219,7 +2219,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             return;
         }
         if (has_tile)
-            (void)tile_work<METHOD, FLUX, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, A.lnprob, A.flux_stride VP_STAMP_PASS, daw_ready);
+            (void)tile_work<METHOD, FLUX, false, true, true, !CLUSTERS, false, false, false, CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, A.lnprob, A.flux_stride VP_STAMP_PASS, daw_ready);
         return;
     }
     if (!oobw) {
@@ -2227,7 +2227,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         // can be scheduled above it
         unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
         asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-        const double wsum = has_tile ? wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS, daw_ready)) : 0.0;
+        const double wsum = has_tile ? wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS, false, false, false, CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS, daw_ready)) : 0.0;
         if (lane == 0) red[SPLIT ? wid : tw] = wsum;
         __syncthreads();
         VP_STAMP(5);
