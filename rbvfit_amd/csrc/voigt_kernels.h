@@ -1191,7 +1191,9 @@ __device__ __forceinline__ int next_near_line(unsigned long long nearm, int from
 // GENERIC = false: the fast instance (no out-of-line generic Faddeeva, 77 VGPRs); lines outside the
 // fast domain poison tau with NaN there, their walkers belong to the GENERIC = true launch.
 template <int METHOD, int OUT, bool GENERIC, bool SOLO, bool PRE = true, bool PAIR = false, bool FF = false, bool W1 = false, bool NANFIX = false,
-          bool MP = true>      // MP = false: the records hold no multipole clusters (walker_kernel's plain instances): the path is not compiled
+          bool MP = true>      // MP = false: the multipole path is not compiled.  (Tried for walker_kernel's plain instances, whose records hold no
+                               //  clusters: 1.4 KB less code, 256 walkers 15.55 -> 15.47 us, 512 unchanged, but 1.3 % MORE VALU instructions
+                               //  issued per eval -- another schedule of the pass loop; not used.  profiles/r05_experiments/ab3)
 __device__ __forceinline__ double tile_work(const InstDev& I, rec_t lcw, double* __restrict__ fl, int p0, int nout, int w,
                                             int tid, int nthreads, const TilePre& pre, bool first,
                                             double* __restrict__ out, int out_stride VP_STAMP_ARG, bool daw_ready = false,
@@ -2219,7 +2221,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
             return;
         }
         if (has_tile)
-            (void)tile_work<METHOD, FLUX, false, true, true, !CLUSTERS, false, false, false, CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, A.lnprob, A.flux_stride VP_STAMP_PASS, daw_ready);
+            (void)tile_work<METHOD, FLUX, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, A.lnprob, A.flux_stride VP_STAMP_PASS, daw_ready);
         return;
     }
     if (!oobw) {
@@ -2227,7 +2229,7 @@ __device__ __forceinline__ void walker_body(InstDev I0, InstDev I1, InstDev I2, 
         // can be scheduled above it
         unsigned long long pr = reinterpret_cast<unsigned long long>(lcw), pq;
         asm volatile("s_mov_b64 %0, %1" : "=s"(pq) : "s"(pr) : "memory");
-        const double wsum = has_tile ? wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS, false, false, false, CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS, daw_ready)) : 0.0;
+        const double wsum = has_tile ? wave_sum(tile_work<METHOD, 0, false, true, true, !CLUSTERS>(I, (rec_t)pq, fl, p0, nout, w, lane, 64, pre, false, nullptr, 0 VP_STAMP_PASS, daw_ready)) : 0.0;
         if (lane == 0) red[SPLIT ? wid : tw] = wsum;
         __syncthreads();
         VP_STAMP(5);
