@@ -166,10 +166,46 @@ def _describe(wl):
             for d, sp in zip(wl.tables, wl.spectra)]
 
 
+def cpu_quota():
+    """CPUs the container may actually use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            return max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        if q > 0:
+            return max(1, int(round(q / per)))
+    except Exception:
+        pass
+    return None
+
+
 def host_cores():
-    """Cores the CPU-baseline legs use: every core this process may run on (its affinity mask = the box's CPU share), or
-    BENCH_CPU_CORES; at most 128 workers (the GPU boxes limit the number of processes a job may hold)."""
-    n = int(os.environ.get("BENCH_CPU_CORES", "0")) or len(os.sched_getaffinity(0))
+    """Workers of the CPU-baseline legs: every core this process may use -- its affinity mask, cut to the container's CPU quota
+    where one is set (a GPU box reports the whole host's cores, 128 on the round-5 boxes, while the job's share is 16: with 128
+    workers the fork Pool measured 9.4 k evals/s and the OpenMP leg 12.8 k against 17.8 k / 23 k with 16) -- or BENCH_CPU_CORES;
+    at most 128 (the GPU boxes limit the number of processes a job may hold)."""
+    n = int(os.environ.get("BENCH_CPU_CORES", "0"))
+    if n <= 0:
+        n = len(os.sched_getaffinity(0))
+        q = cpu_quota()
+        if q:
+            n = min(n, q)
+        else:
+            # no readable quota: a GPU box shares its host's cores among its GPUs' jobs, 16 per GPU (counting the devices does not
+            # initialise the GPU, so the fork Pool can still be made afterwards)
+            try:
+                import torch
+                n = min(n, 16 * max(1, torch.cuda.device_count()))
+            except Exception:
+                n = min(n, 16)
     return max(1, min(128, n))
 
 
@@ -183,7 +219,7 @@ def cpu_pool_baseline(pool, cores, wl, budget_s=5.0):
         out = pool.map(_pool_chunk, tasks, chunksize=1)
         n += sum(len(o) for o in out)
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, cores=cores, cores_reported=os.cpu_count(), kind="port",
+    return dict(value=n / dt, cores=cores, cores_reported=os.cpu_count(), cpu_quota=cpu_quota(), kind="port",
                 sample=f"{n} lnprob calls through multiprocessing fork Pool({cores}).map over the {wl.name} "
                        f"walker rows ({dt:.1f} s, numpy/scipy oracle)")
 
@@ -221,7 +257,7 @@ def cpu_baseline(wl, budget_s=12.0):
             reps += 1
         dtc = time.perf_counter() - t0
         m = min(len(cvals), len(vals))
-        base["c_openmp"] = dict(value=reps * len(sub) / dtc, cores=cores, cores_reported=os.cpu_count(), kind="port",
+        base["c_openmp"] = dict(value=reps * len(sub) / dtc, cores=cores, cores_reported=os.cpu_count(), cpu_quota=cpu_quota(), kind="port",
                                 sample=f"{reps} x {len(sub)} walkers, oracle/voigt_oracle.c, OpenMP",
                                 max_rel_vs_numpy_oracle=float(np.max(np.abs(cvals[:m] / np.array(vals[:m]) - 1))))
     except Exception as e:                                   # the C oracle is optional for the baseline

@@ -24,6 +24,10 @@ def main():
     ref.set_option("prearm", 0)
     eng.set_option("prearm_us", 150)
     other.set_option("prearm_us", 150)
+    # (round 5: by default a launch waits only as long as the caller's rhythm suggests and a caller whose launches expire is left
+    #  alone for a while -- with this script's random pauses almost nothing would be pre-armed: "prearm" = 1 arms after every
+    #  eligible call and waits the whole prearm_us, which is what a soak of the PROTOCOL wants)
+    eng.set_option("prearm", 1)
     lb, ub = np.asarray(wl.lb), np.asarray(wl.ub)
     base = np.ascontiguousarray(wl.thetas)
     batches = []
