@@ -587,18 +587,23 @@ def rank_main(args):
         # interval -- 8-10 % on a 200-700 us kernel, more on a 30 us one -- so they are only used for the SHARE of the
         # step each kernel kind takes; the step itself is timed by ONE pair of events around nprof back-to-back passes
         # (no per-launch records), and the dominant kernel's duration is that step time x its share / its launches.
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(nprof):
-            eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        step_ev_ms = e0.elapsed_time(e1) / nprof
+        # (seven such blocks, the median: one block of a 20 us pass is 4 ms, short enough for one clock ramp or one
+        # neighbour's burst on the box to move it by 20 %)
+        step_samples = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(nprof):
+                eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            step_samples.append(e0.elapsed_time(e1) / nprof)
+        step_ev_ms = float(np.median(step_samples))
         ev_total = pr["prep_ms"] + pr["tile_ms"] + pr.get("finalize_ms", 0.0)
         launches_per_step = max(pr["n_tile_launches"], 1) / nprof
         share = pr["tile_ms"] / ev_total if ev_total > 0 else 1.0
         tile_ms = step_ev_ms * share / launches_per_step
-        timing_note = (f"HIP events on the launch stream: one pair around {nprof} back-to-back passes gives the step time "
+        timing_note = (f"HIP events on the launch stream: one pair around {nprof} back-to-back passes (median of 7 such blocks) gives the step time "
                        f"({1e3 * step_ev_ms:.2f} us); per-launch event pairs give the dominant kernel's share of it ({share:.3f}, "
                        f"{launches_per_step:.0f} launch(es) per step)")
         bytes_per_launch = wl.algorithmic_bytes_per_eval * W / len(wl.pixels)

@@ -31,6 +31,7 @@ def main():
         NT = min(16, int(wl.engine._lib.vp_instrument_pixels(wl.engine._ctx, 0) and (os.environ.get("TIMELINE_TILES") or 12)))
         eng = wl.engine
         eng.set_option("walker", 1)
+        eng.set_option("prearm", 0)          # (the ordinary launch: a pre-armed one spends its entry waiting for the host)
         for _ in range(20):
             eng.lnprob(wl.thetas)
         assert eng.last_launch_kind == "walker"
