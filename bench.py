@@ -821,6 +821,46 @@ def rank_main(args):
             except Exception as e:
                 multi_info = {"error": str(e)}
 
+    side_info = None
+    if rank == 0 and not args.no_extras and args.config in ("C0", "C1"):
+        # Two independent ensembles (two contexts, two streams) evaluated side by side: what one GPU sustains for a caller with more
+        # than one chain in flight (tempered chains, several absorbers fitted at once).  A lone stream of dependent passes leaves
+        # the SIMDs idle through every launch's entry; a second stream's passes move into those gaps.  Not `value`.
+        try:
+            from rbvfit_amd.workloads import make_workload as _mk
+            wl2 = _mk(args.config, walkers=W, device_id=local_rank, walker_seed=101 + rank)
+            th2 = torch.from_numpy(wl2.thetas).cuda()
+            out2 = torch.empty(W, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+
+            # (stream handle 0 = each context's OWN stream, made by the library: those run side by side.  Two streams of torch's
+            #  pool did not on this stack -- 45.4 us per pair of 512-walker passes against 39.7, 31.5 against 20.2 at 256,
+            #  scripts/side_by_side.py -- they seem to share a hardware queue)
+            def both():
+                eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, 0)
+                wl2.engine.lnprob_device(th2.data_ptr(), out2.data_ptr(), W, 0)
+            for _ in range(200):
+                both()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                for _ in range(400):
+                    both()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / 400)
+            pair_s = float(np.median(ts))
+            chk = wl2.engine.lnprob(wl2.thetas)
+            assert np.array_equal(out2.cpu().numpy(), chk, equal_nan=True), "side-by-side pass differs from the context's own"
+            side_info = dict(evals_per_sec=2 * W / pair_s, us_per_pair_of_passes=1e6 * pair_s, us_per_pass_one_stream=1e3 * step_ev_ms,
+                             note="two contexts of W walkers each on their own streams, passes enqueued alternately; wall time over 400 pairs, "
+                                  "median of 7; the second context's result checked against its own lone pass")
+            wl2.engine.close()
+            eng.lnprob_device(d_theta.data_ptr(), d_out.data_ptr(), W, stream.cuda_stream)
+            torch.cuda.synchronize()
+        except Exception as e:                                   # (an extra: never fails the line)
+            side_info = {"error": str(e)}
+
     result = d_out.cpu().numpy()
     if rank == 0:
         evals = W * world * args.steps
@@ -860,6 +900,7 @@ def rank_main(args):
             "walker_spread": spread_note,
             "posterior_spread": spread_info if not args.no_extras else None,
             "sharded_sampler_one_gpu": multi_info if not args.no_extras else None,
+            "two_ensembles_side_by_side": side_info,
             "roofline": roof,
         }
         if use_dist:
