@@ -294,8 +294,8 @@ const char* vp_multi_last_error(const vp_multi* m);
 /* The context's own stream (a hipStream_t, created non-blocking): what hip_stream == NULL selects in the
  * *_device entry points.  Lets a host framework order its own work against it (e.g.
  * torch.cuda.ExternalStream(handle).wait_stream(...)).  Batches of DIFFERENT contexts enqueued on their own streams run side by
- * side on the GPU -- independent ensembles fill each other's launch entries: measured 28.3 M evals/s for two 512-walker C1
- * ensembles against 23.8 M for one, 27.6 M against 16.5 M at 256 (bench.py, "two_ensembles_side_by_side"); two streams taken from
+ * side on the GPU -- independent ensembles fill each other's launch entries: measured 28.8 M evals/s for two 512-walker C1
+ * ensembles against 24.2 M for one, 27.6 M against 16.5 M at 256 (bench.py, "two_ensembles_side_by_side"); two streams taken from
  * torch's pool did not overlap on ROCm 7.2 / torch 2.10, so pass NULL (or this handle) where that matters. */
 void* vp_ctx_stream(const vp_ctx* ctx);
 
