@@ -1181,6 +1181,20 @@ __device__ __forceinline__ void lsf_block6(const InstDev& I, const double* __res
         }
         return;
     }
+    if (OUT != 0 && !NANFIX && o0 + LSF_PX <= nout) {
+        // flux output, a lane with all six pixels inside the tile: three 16-byte stores from one address (the row's last lanes,
+        // which may not write past the tile, take the pixel-by-pixel form below)
+        typedef obs2_u_t __attribute__((address_space(1)))* out2_ptr_t;
+        const out2_ptr_t o2 = (out2_ptr_t)((const double __attribute__((address_space(1)))*)reinterpret_cast<unsigned long long>(out) +
+                                           ((size_t)w * out_stride + p0 + o0));
+#pragma unroll
+        for (int p = 0; p < LSF_PX; p += 2) {
+            obs2_t v;
+            v.x = m[p]; v.y = m[p + 1];
+            o2[p >> 1] = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < LSF_PX; ++p) {
         const int px = p0 + o0 + p;
